@@ -1,0 +1,180 @@
+// oracle/hlsl.h -- TEST INFRASTRUCTURE ONLY (CPU oracle).  Not part of the product: nothing
+// under gltf_renderer_amd/ may include, link or call this.
+//
+// Minimal HLSL-semantics vector layer for the CPU restatement of the reference shaders
+// (SURVEY.md section 10 cheat-sheet).  Scalar fp32 everywhere; compile without fast-math and
+// with -ffp-contract=off so the arithmetic is what is written.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+namespace hlsl {
+
+static const float PI = 3.14159265359f;   // Common.hlsli:8
+static const float TAU = 2 * PI;          // Common.hlsli:9
+
+struct float2 { float x, y; };
+struct float3 { float x, y, z; };
+struct float4 { float x, y, z, w; };
+struct uint2 { uint32_t x, y; };
+struct uint4 { uint32_t x, y, z, w; };
+struct int2 { int x, y; };
+
+inline float2 F2(float a) { return {a, a}; }
+inline float3 F3(float a) { return {a, a, a}; }
+inline float4 F4(float a) { return {a, a, a, a}; }
+inline float4 F4(float3 v, float w) { return {v.x, v.y, v.z, w}; }
+inline float3 xyz(float4 v) { return {v.x, v.y, v.z}; }
+inline float2 xy(float3 v) { return {v.x, v.y}; }
+inline float2 xy(float4 v) { return {v.x, v.y}; }
+
+#define HLSL_OP2(T, op)                                                                      \
+    inline T operator op(T a, T b);                                                          \
+    inline T operator op(T a, float b);                                                      \
+    inline T operator op(float a, T b);
+inline float2 operator+(float2 a, float2 b) { return {a.x + b.x, a.y + b.y}; }
+inline float2 operator-(float2 a, float2 b) { return {a.x - b.x, a.y - b.y}; }
+inline float2 operator*(float2 a, float2 b) { return {a.x * b.x, a.y * b.y}; }
+inline float2 operator/(float2 a, float2 b) { return {a.x / b.x, a.y / b.y}; }
+inline float2 operator+(float2 a, float b) { return {a.x + b, a.y + b}; }
+inline float2 operator-(float2 a, float b) { return {a.x - b, a.y - b}; }
+inline float2 operator*(float2 a, float b) { return {a.x * b, a.y * b}; }
+inline float2 operator/(float2 a, float b) { return {a.x / b, a.y / b}; }
+inline float2 operator*(float a, float2 b) { return {a * b.x, a * b.y}; }
+inline float2 operator-(float2 a) { return {-a.x, -a.y}; }
+
+inline float3 operator+(float3 a, float3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline float3 operator-(float3 a, float3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline float3 operator*(float3 a, float3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline float3 operator/(float3 a, float3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+inline float3 operator+(float3 a, float b) { return {a.x + b, a.y + b, a.z + b}; }
+inline float3 operator-(float3 a, float b) { return {a.x - b, a.y - b, a.z - b}; }
+inline float3 operator*(float3 a, float b) { return {a.x * b, a.y * b, a.z * b}; }
+inline float3 operator/(float3 a, float b) { return {a.x / b, a.y / b, a.z / b}; }
+inline float3 operator+(float a, float3 b) { return {a + b.x, a + b.y, a + b.z}; }
+inline float3 operator-(float a, float3 b) { return {a - b.x, a - b.y, a - b.z}; }
+inline float3 operator*(float a, float3 b) { return {a * b.x, a * b.y, a * b.z}; }
+inline float3 operator-(float3 a) { return {-a.x, -a.y, -a.z}; }
+inline float3& operator+=(float3& a, float3 b) { a = a + b; return a; }
+inline float3& operator*=(float3& a, float3 b) { a = a * b; return a; }
+inline float3& operator*=(float3& a, float b) { a = a * b; return a; }
+inline float3& operator/=(float3& a, float b) { a = a / b; return a; }
+
+inline float4 operator+(float4 a, float4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+inline float4 operator-(float4 a, float4 b) { return {a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; }
+inline float4 operator*(float4 a, float4 b) { return {a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+inline float4 operator*(float4 a, float b) { return {a.x * b, a.y * b, a.z * b, a.w * b}; }
+inline float4 operator*(float a, float4 b) { return {a * b.x, a * b.y, a * b.z, a * b.w}; }
+inline float4 operator/(float4 a, float b) { return {a.x / b, a.y / b, a.z / b, a.w / b}; }
+inline float4 operator-(float4 a) { return {-a.x, -a.y, -a.z, -a.w}; }
+
+inline float dot(float2 a, float2 b) { return a.x * b.x + a.y * b.y; }
+inline float dot(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline float dot(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+inline float3 cross(float3 a, float3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+inline float length(float2 v) { return sqrtf(dot(v, v)); }
+inline float length(float3 v) { return sqrtf(dot(v, v)); }
+// normalize(v) = v * rsqrt(dot(v,v)): NaN for the zero vector (scrubbed per sample later).
+inline float2 normalize(float2 v) { return v / sqrtf(dot(v, v)); }
+inline float3 normalize(float3 v) { return v / sqrtf(dot(v, v)); }
+inline float4 normalize(float4 v) { return v / sqrtf(dot(v, v)); }
+
+// HLSL min/max return the non-NaN operand: exactly fminf/fmaxf.
+inline float hmin(float a, float b) { return fminf(a, b); }
+inline float hmax(float a, float b) { return fmaxf(a, b); }
+inline float2 hmax(float2 a, float2 b) { return {hmax(a.x, b.x), hmax(a.y, b.y)}; }
+inline float3 hmin(float3 a, float3 b) { return {hmin(a.x, b.x), hmin(a.y, b.y), hmin(a.z, b.z)}; }
+inline float3 hmax(float3 a, float3 b) { return {hmax(a.x, b.x), hmax(a.y, b.y), hmax(a.z, b.z)}; }
+inline float clamp(float x, float a, float b) { return hmin(hmax(x, a), b); }
+inline float3 clamp(float3 v, float a, float b) { return {clamp(v.x, a, b), clamp(v.y, a, b), clamp(v.z, a, b)}; }
+inline float saturate(float x) { return hmin(hmax(x, 0.0f), 1.0f); }   // NaN -> 0
+inline float3 saturate(float3 v) { return {saturate(v.x), saturate(v.y), saturate(v.z)}; }
+inline float lerp(float a, float b, float t) { return a + t * (b - a); }
+inline float3 lerp(float3 a, float3 b, float t) { return a + t * (b - a); }
+inline float3 lerp(float3 a, float3 b, float3 t) { return a + t * (b - a); }
+inline float4 lerp(float4 a, float4 b, float t) { return a + t * (b - a); }
+inline float sign(float x) { return x > 0 ? 1.0f : (x < 0 ? -1.0f : 0.0f); }  // sign(0) = 0
+inline float3 reflect(float3 i, float3 n) { return i - 2 * dot(n, i) * n; }
+// pow(x,y) = exp2(y*log2(x)): x<0 -> NaN, pow(0, y>0) = 0.
+inline float hpow(float x, float y) { return exp2f(y * log2f(x)); }
+inline float3 hpow(float3 v, float y) { return {hpow(v.x, y), hpow(v.y, y), hpow(v.z, y)}; }
+inline float3 habs(float3 v) { return {fabsf(v.x), fabsf(v.y), fabsf(v.z)}; }
+inline bool any_gt0(float3 v) { return v.x > 0 || v.y > 0 || v.z > 0; }
+inline bool any_nan(float3 v) { return std::isnan(v.x) || std::isnan(v.y) || std::isnan(v.z); }
+inline bool any_inf(float3 v) { return std::isinf(v.x) || std::isinf(v.y) || std::isinf(v.z); }
+inline int asint(float f) { int i; memcpy(&i, &f, 4); return i; }
+inline float asfloat(int i) { float f; memcpy(&f, &i, 4); return f; }
+// (int)(float): truncate toward zero; keep it defined for NaN / out of range.
+inline int f2i(float f) {
+    if (!(f == f)) return 0;
+    if (f >= 2147483520.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (int)0x80000000;
+    return (int)f;
+}
+// (uint)(float): negative / NaN -> 0.
+inline uint32_t f2u(float f) {
+    if (!(f > 0)) return 0;
+    if (f >= 4294967040.0f) return 0xffffffffu;
+    return (uint32_t)f;
+}
+
+// float4x4 as stored by glm (column-major, m[col*4+row]); mul(M, v) = ordinary M*v.
+struct float4x4 { float m[16]; };
+inline float4 mul(const float4x4& M, float4 v) {
+    float4 r;
+    r.x = M.m[0] * v.x + M.m[4] * v.y + M.m[8] * v.z + M.m[12] * v.w;
+    r.y = M.m[1] * v.x + M.m[5] * v.y + M.m[9] * v.z + M.m[13] * v.w;
+    r.z = M.m[2] * v.x + M.m[6] * v.y + M.m[10] * v.z + M.m[14] * v.w;
+    r.w = M.m[3] * v.x + M.m[7] * v.y + M.m[11] * v.z + M.m[15] * v.w;
+    return r;
+}
+// float3x3(a,b,c) has ROWS a,b,c; mul(M,v) = (a.v, b.v, c.v).
+struct float3x3 { float3 r0, r1, r2; };
+inline float3x3 M3(float3 a, float3 b, float3 c) { return {a, b, c}; }
+inline float3 mul(const float3x3& M, float3 v) { return {dot(M.r0, v), dot(M.r1, v), dot(M.r2, v)}; }
+inline float3x3 transpose(const float3x3& M) {
+    return {{M.r0.x, M.r1.x, M.r2.x}, {M.r0.y, M.r1.y, M.r2.y}, {M.r0.z, M.r1.z, M.r2.z}};
+}
+inline float3x3 mul(const float3x3& A, const float3x3& B) {
+    float3x3 Bt = transpose(B);
+    return {{dot(A.r0, Bt.r0), dot(A.r0, Bt.r1), dot(A.r0, Bt.r2)},
+            {dot(A.r1, Bt.r0), dot(A.r1, Bt.r1), dot(A.r1, Bt.r2)},
+            {dot(A.r2, Bt.r0), dot(A.r2, Bt.r1), dot(A.r2, Bt.r2)}};
+}
+
+// IEEE binary16 <-> binary32 (round to nearest even; overflow -> inf, as R16G16B16A16_FLOAT).
+inline float half_to_float(uint16_t h) {
+    uint32_t s = (h >> 15) & 1, e = (h >> 10) & 0x1f, m = h & 0x3ff, out;
+    if (e == 0) {
+        if (m == 0) out = s << 31;
+        else {
+            int sh = 0;
+            while (!(m & 0x400)) { m <<= 1; sh++; }
+            m &= 0x3ff;
+            out = (s << 31) | ((uint32_t)(127 - 15 - sh + 1) << 23) | (m << 13);
+        }
+    } else if (e == 31) out = (s << 31) | 0x7f800000u | (m << 13);
+    else out = (s << 31) | ((e + 112) << 23) | (m << 13);
+    float f; memcpy(&f, &out, 4); return f;
+}
+inline uint16_t float_to_half(float f) {
+    uint32_t x; memcpy(&x, &f, 4);
+    uint32_t s = (x >> 16) & 0x8000u; x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(s | 0x7c00u | ((x > 0x7f800000u) ? 0x200u : 0));
+    if (x >= 0x477ff000u) return (uint16_t)(s | 0x7c00u);               // >= 65520 -> inf
+    if (x < 0x33000001u) return (uint16_t)s;                              // < 2^-25 -> 0
+    int e = (int)(x >> 23) - 127;
+    uint32_t m = (x & 0x7fffffu) | 0x800000u;
+    int shift = (e < -14) ? (13 + (-14 - e)) : 13;
+    uint32_t hm = m >> shift, rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (hm & 1))) hm++;
+    uint32_t he = (e < -14) ? 0 : (uint32_t)(e + 15);
+    // hm holds the implicit bit for normals: adding it to (he-1)<<10 carries correctly.
+    uint32_t out = (e < -14) ? hm : (((he - 1) << 10) + hm);
+    return (uint16_t)(s | out);
+}
+
+}  // namespace hlsl
