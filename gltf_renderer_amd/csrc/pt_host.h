@@ -1,0 +1,61 @@
+// pt_host.h -- host-visible declarations shared by the translation units of libmipt.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "pt_types.h"
+
+namespace pt {
+
+// ---- accel.hip --------------------------------------------------------------------------------
+struct AccelScratch {
+    TriPacket* tris_unsorted = nullptr;
+    uint64_t *keys_a = nullptr, *keys_b = nullptr;
+    uint32_t *vals_a = nullptr, *vals_b = nullptr;
+    int32_t* leaf_parent = nullptr;
+    int32_t* node_parent = nullptr;
+    uint32_t* flags = nullptr;
+    uint32_t* bounds = nullptr;      // 6 sortable-uint floats: min xyz, max xyz
+    void* sort_temp = nullptr;
+    size_t sort_temp_bytes = 0;
+    size_t capacity = 0;
+};
+void accel_scratch_free(AccelScratch& s);
+hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const InstanceRec* d_instances, int n_inst, uint32_t n_tris, BvhNode* d_nodes,
+                       TriPacket* d_tris, int32_t* root_out, hipStream_t stream);
+
+// ---- envmap.hip -------------------------------------------------------------------------------
+struct EnvDevice {
+    uint16_t* cube = nullptr;          // all mips, RGBA16F
+    size_t mip_offset[16] = {0};       // in halfs
+    int mip_n[16] = {0};
+    int mips = 0;
+    float* importance = nullptr;       // sum pyramid
+    uint32_t level_offset[12] = {0};
+    int levels = 0;
+    int imp_res = 1024;
+};
+hipError_t env_build(EnvDevice& e, const float* d_equirect, int w, int h, hipStream_t stream);
+void env_free(EnvDevice& e);
+
+// ---- skin_tonemap.hip -------------------------------------------------------------------------
+struct SkinArgs {
+    uint32_t num_of_vertices, input_mesh_flags, output_mesh_flags;
+    int32_t num_of_morph_targets;
+    float morph_weight[4];
+    const float* morph_position[4];
+    const uint32_t* morph_tangent_space[4];
+    const float* in_position;
+    const uint32_t* in_tangent_space;
+    const uint4* in_joint_weight;
+    const pt_bone* bones;
+    int32_t bone_count;
+    float* out_position;
+    uint32_t* out_tangent_space;
+};
+void launch_skin(const SkinArgs& a, bool use_mfma, hipStream_t stream);
+void launch_tonemap(const float4* in, uint32_t w, uint32_t h, const pt_tonemap_config& cfg, float* out_rgb, uint32_t* out_rgba8, hipStream_t stream);
+
+// ---- pt_kernel.hip ----------------------------------------------------------------------------
+void launch_megakernel(const SceneRec& sc, const FrameConstants& fc, float4* output, Counters* counters, bool count, hipStream_t stream);
+
+}  // namespace pt

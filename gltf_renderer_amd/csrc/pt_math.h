@@ -1,0 +1,103 @@
+// pt_math.h -- device vector math with HLSL semantics for the gfx950 path-tracing kernels.
+// (saturate NaN->0, sign(0)=0, pow = exp2(y*log2 x), normalize(0)=NaN,
+//  min/max return the non-NaN operand.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#define PT_DEV __device__ __forceinline__
+
+namespace pt {
+
+constexpr float kPi = 3.14159265359f;      // Common.hlsli:8
+constexpr float kTau = 2.0f * kPi;         // Common.hlsli:9
+
+struct vec2 { float x, y; };
+struct vec3 { float x, y, z; };
+struct vec4 { float x, y, z, w; };
+
+PT_DEV vec3 v3(float a) { return {a, a, a}; }
+PT_DEV vec3 v3(float x, float y, float z) { return {x, y, z}; }
+PT_DEV vec3 v3p(const float* p) { return {p[0], p[1], p[2]}; }
+PT_DEV vec3 xyz(vec4 v) { return {v.x, v.y, v.z}; }
+
+PT_DEV vec2 operator+(vec2 a, vec2 b) { return {a.x + b.x, a.y + b.y}; }
+PT_DEV vec2 operator-(vec2 a, vec2 b) { return {a.x - b.x, a.y - b.y}; }
+PT_DEV vec2 operator*(vec2 a, float b) { return {a.x * b, a.y * b}; }
+PT_DEV vec2 operator*(float a, vec2 b) { return {a * b.x, a * b.y}; }
+
+PT_DEV vec3 operator+(vec3 a, vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+PT_DEV vec3 operator-(vec3 a, vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+PT_DEV vec3 operator*(vec3 a, vec3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+PT_DEV vec3 operator/(vec3 a, vec3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+PT_DEV vec3 operator+(vec3 a, float b) { return {a.x + b, a.y + b, a.z + b}; }
+PT_DEV vec3 operator-(vec3 a, float b) { return {a.x - b, a.y - b, a.z - b}; }
+PT_DEV vec3 operator*(vec3 a, float b) { return {a.x * b, a.y * b, a.z * b}; }
+PT_DEV vec3 operator/(vec3 a, float b) { return {a.x / b, a.y / b, a.z / b}; }
+PT_DEV vec3 operator*(float a, vec3 b) { return {a * b.x, a * b.y, a * b.z}; }
+PT_DEV vec3 operator+(float a, vec3 b) { return {a + b.x, a + b.y, a + b.z}; }
+PT_DEV vec3 operator-(float a, vec3 b) { return {a - b.x, a - b.y, a - b.z}; }
+PT_DEV vec3 operator-(vec3 a) { return {-a.x, -a.y, -a.z}; }
+PT_DEV vec3& operator+=(vec3& a, vec3 b) { a = a + b; return a; }
+PT_DEV vec3& operator*=(vec3& a, vec3 b) { a = a * b; return a; }
+PT_DEV vec3& operator*=(vec3& a, float b) { a = a * b; return a; }
+PT_DEV vec4 operator+(vec4 a, vec4 b) { return {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+PT_DEV vec4 operator*(vec4 a, vec4 b) { return {a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; }
+PT_DEV vec4 operator*(vec4 a, float b) { return {a.x * b, a.y * b, a.z * b, a.w * b}; }
+
+PT_DEV float dot(vec2 a, vec2 b) { return a.x * b.x + a.y * b.y; }
+PT_DEV float dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PT_DEV vec3 cross(vec3 a, vec3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+PT_DEV float length(vec3 v) { return sqrtf(dot(v, v)); }
+PT_DEV vec3 normalize(vec3 v) { return v / sqrtf(dot(v, v)); }
+PT_DEV vec2 normalize(vec2 v) { float l = sqrtf(dot(v, v)); return {v.x / l, v.y / l}; }
+
+PT_DEV float hmin(float a, float b) { return fminf(a, b); }
+PT_DEV float hmax(float a, float b) { return fmaxf(a, b); }
+PT_DEV vec3 hmin(vec3 a, vec3 b) { return {fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)}; }
+PT_DEV vec3 hmax(vec3 a, vec3 b) { return {fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)}; }
+PT_DEV float clampf(float x, float a, float b) { return fminf(fmaxf(x, a), b); }
+PT_DEV float saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+PT_DEV float lerpf(float a, float b, float t) { return a + t * (b - a); }
+PT_DEV vec3 lerp3(vec3 a, vec3 b, float t) { return a + t * (b - a); }
+PT_DEV float signf(float x) { return x > 0 ? 1.0f : (x < 0 ? -1.0f : 0.0f); }
+PT_DEV vec3 reflect(vec3 i, vec3 n) { return i - 2 * dot(n, i) * n; }
+PT_DEV float hpow(float x, float y) { return exp2f(y * log2f(x)); }
+PT_DEV float max3(vec3 c) { return fmaxf(fmaxf(c.x, c.y), c.z); }
+PT_DEV bool any_gt0(vec3 v) { return v.x > 0 || v.y > 0 || v.z > 0; }
+PT_DEV bool any_nan(vec3 v) { return (v.x != v.x) || (v.y != v.y) || (v.z != v.z); }
+PT_DEV bool any_inf(vec3 v) { return isinf(v.x) || isinf(v.y) || isinf(v.z); }
+PT_DEV float heavyside(float a) { return a > 0 ? 1.f : 0.f; }
+// (int)(float) / (uint)(float) with defined behaviour for NaN and overflow.
+PT_DEV int f2i(float f) {
+    if (!(f == f)) return 0;
+    if (f >= 2147483520.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (int)0x80000000;
+    return (int)f;
+}
+PT_DEV uint32_t f2u(float f) {
+    if (!(f > 0)) return 0;
+    if (f >= 4294967040.0f) return 0xffffffffu;
+    return (uint32_t)f;
+}
+// column-major 4x4 (glm) times (v,1) / (v,0), xyz only
+PT_DEV vec3 mul_point(const float* M, vec3 v) {
+    return {M[0] * v.x + M[4] * v.y + M[8] * v.z + M[12], M[1] * v.x + M[5] * v.y + M[9] * v.z + M[13],
+            M[2] * v.x + M[6] * v.y + M[10] * v.z + M[14]};
+}
+PT_DEV vec3 mul_dir(const float* M, vec3 v) {
+    return {M[0] * v.x + M[4] * v.y + M[8] * v.z, M[1] * v.x + M[5] * v.y + M[9] * v.z, M[2] * v.x + M[6] * v.y + M[10] * v.z};
+}
+PT_DEV vec4 mul4(const float* M, vec4 v) {
+    return {M[0] * v.x + M[4] * v.y + M[8] * v.z + M[12] * v.w, M[1] * v.x + M[5] * v.y + M[9] * v.z + M[13] * v.w,
+            M[2] * v.x + M[6] * v.y + M[10] * v.z + M[14] * v.w, M[3] * v.x + M[7] * v.y + M[11] * v.z + M[15] * v.w};
+}
+// frame (t, b, n): to_local(v) = (t.v, b.v, n.v); to_world(h) = t*h.x + b*h.y + n*h.z
+PT_DEV vec3 to_local(vec3 t, vec3 b, vec3 n, vec3 v) { return {dot(t, v), dot(b, v), dot(n, v)}; }
+PT_DEV vec3 to_world(vec3 t, vec3 b, vec3 n, vec3 h) {
+    return {t.x * h.x + b.x * h.y + n.x * h.z, t.y * h.x + b.y * h.y + n.y * h.z, t.z * h.x + b.z * h.y + n.z * h.z};
+}
+PT_DEV float half_bits_to_float(uint16_t h) { return __half2float(__ushort_as_half(h)); }
+
+}  // namespace pt

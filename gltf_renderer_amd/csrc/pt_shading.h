@@ -1,0 +1,690 @@
+// pt_shading.h -- device shading library of the gfx950 path tracer.
+//
+// Computes what the reference's shading headers compute (cited per function, file:line relative to the
+// reference root), arranged for an iterative register-resident path state instead of DXR recursion:
+// per hit the lobe probabilities are formed once and shared by the environment-NEE, light-NEE and
+// BSDF-sampling evaluations; texture filtering and cube-map filtering are software (CDNA4 has no
+// texture units reachable from HIP).
+#pragma once
+#include "pt_math.h"
+#include "pt_types.h"
+
+namespace pt {
+
+constexpr float kMinRoughness = 0.001f;    // Bsdf.hlsli:26
+
+// ---------------------------------------------------------------- RNG (Random.hlsli:17-30, PathTracer.lib.hlsl:144-148)
+PT_DEV vec4 next_random(uint32_t px, uint32_t py, uint32_t seed, int& count) {
+    uint32_t x = px * 1664525u + 1013904223u, y = py * 1664525u + 1013904223u;
+    uint32_t z = seed * 1664525u + 1013904223u, w = (uint32_t)count * 1664525u + 1013904223u;
+    count++;
+    x += y * w; y += z * x; z += x * y; w += y * z;
+    x ^= x >> 16; y ^= y >> 16; z ^= z >> 16; w ^= w >> 16;
+    x += y * w; y += z * x; z += x * y; w += y * z;
+    const float s = 2.3283064365386963e-10f;      // 2^-32: the fp32 value of the literal 4294967295.0 is 2^32 (quirk q29)
+    return {(float)x * s, (float)y * s, (float)z * s, (float)w * s};
+}
+
+// ---------------------------------------------------------------- Vertex.hlsli / Common.hlsli
+PT_DEV vec3 decode_octahedral(float ex, float ey) {                // Common.hlsli:90-103
+    float z = 1.f - fabsf(ex) - fabsf(ey);
+    float x = ex, y = ey;
+    if (!(z >= 0.f)) {
+        x = (ex >= 0 ? 1.f : -1.f) * (1.f - fabsf(ey));
+        y = (ey >= 0 ? 1.f : -1.f) * (1.f - fabsf(ex));
+    }
+    return normalize(v3(x, y, z));
+}
+PT_DEV vec2 encode_octahedral(vec3 n) {                            // Common.hlsli:76-88
+    float s = fabsf(n.x) + fabsf(n.y) + fabsf(n.z);
+    float ox = n.x / s, oy = n.y / s, oz = n.z / s;
+    if (oz >= 0.f) return {ox, oy};
+    return {(ox >= 0 ? 1.f : -1.f) * (1.f - fabsf(oy)), (oy >= 0 ? 1.f : -1.f) * (1.f - fabsf(ox))};
+}
+PT_DEV void basis_accurate(vec3 n, vec3& b1, vec3& b2) {           // Common.hlsli:46-53
+    float sg = n.z >= 0.0f ? 1.0f : -1.0f;
+    float a = -1.0f / (sg + n.z);
+    float b = n.x * n.y * a;
+    b1 = v3(1.0f + sg * n.x * n.x * a, sg * b, -sg * n.x);
+    b2 = v3(b, sg + n.y * n.y * a, -n.y);
+}
+PT_DEV void basis_simple(vec3 n, vec3& t, vec3& b) {               // Common.hlsli:33-42
+    if (fabsf(n.x) > fabsf(n.z)) b = v3(-n.y, n.x, 0);
+    else b = v3(0, -n.z, n.y);
+    b = normalize(b);
+    t = cross(b, n);
+}
+// R10G10B10A2_UNORM fetch + DecodeTangentSpace (Vertex.hlsli:5-19, 46-50).  Tangent comes out negated (quirk q25).
+PT_DEV void decode_tangent_space(uint32_t p, vec3& normal, vec3& tangent, float& winding) {
+    float ex = (float)(p & 0x3ff) / 1023.f, ey = (float)((p >> 10) & 0x3ff) / 1023.f, ez = (float)((p >> 20) & 0x3ff) / 1023.f;
+    float ew = (float)(p >> 30) / 3.f;
+    normal = decode_octahedral(ex * 2 - 1, ey * 2 - 1);
+    vec3 ct, cb;
+    basis_accurate(normal, ct, cb);
+    float angle = kTau * ez;
+    float sn = sinf(angle), cs = cosf(angle);
+    tangent = cs * ct + sn * cb;
+    winding = ew > 0 ? 1.f : -1.f;
+}
+PT_DEV uint32_t encode_tangent_space(vec3 normal, vec3 tangent, float winding) {    // Vertex.hlsli:21-44
+    vec2 e = encode_octahedral(normal);
+    uint32_t qx = f2u(clampf(0.5f * e.x + 0.5f, 0, 1) * 1023 + 0.5f), qy = f2u(clampf(0.5f * e.y + 0.5f, 0, 1) * 1023 + 0.5f);
+    vec3 nq = decode_octahedral(2.0f * ((float)qx / 1023.0f) - 1.0f, 2.0f * ((float)qy / 1023.0f) - 1.0f);
+    vec3 ct, cb;
+    basis_accurate(nq, ct, cb);
+    float angle = atan2f(dot(tangent, cb), dot(tangent, ct));
+    uint32_t qt = f2u(((angle / kTau) + 0.5f) * 1023 + 0.5f);
+    uint32_t qw = winding == 1 ? 3u : 0u;
+    return qx | (qy << 10) | (qt << 20) | (qw << 30);
+}
+
+// ---------------------------------------------------------------- software texture unit
+PT_DEV int wrap_addr(int i, int n, int mode) {
+    if (mode == PT_ADDRESS_WRAP) { int m = i % n; return m < 0 ? m + n : m; }
+    if (mode == PT_ADDRESS_MIRROR) { int p = 2 * n; int m = i % p; if (m < 0) m += p; return m < n ? m : p - 1 - m; }
+    return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+PT_DEV vec4 unpack_texel(uint32_t t, uint32_t srgb, const float* lut) {
+    uint32_t r = t & 0xff, g = (t >> 8) & 0xff, b = (t >> 16) & 0xff, a = t >> 24;
+    if (srgb) return {lut[r], lut[g], lut[b], (float)a / 255.0f};
+    return {(float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f, (float)a / 255.0f};
+}
+PT_DEV float finite_coord(float x) {
+    if (!(x == x) || isinf(x)) return 0.f;
+    return clampf(x, -1.0e9f, 1.0e9f);
+}
+// Texture2D.SampleLevel(sampler, uv, 0) on an RGBA8 (optionally sRGB) texture: D3D texel-centre rule,
+// sRGB decoded before filtering, fp32 weights.
+PT_DEV vec4 sample_texture2d(const TextureRec& t, const SamplerRec& s, const float* srgb_lut, float u, float v) {
+    float x = finite_coord(u * (float)t.width), y = finite_coord(v * (float)t.height);
+    if (s.mag_filter == PT_FILTER_POINT) {
+        int i = wrap_addr((int)floorf(x), t.width, s.address_u), j = wrap_addr((int)floorf(y), t.height, s.address_v);
+        return unpack_texel(t.texels[(size_t)j * t.width + i], t.srgb, srgb_lut);
+    }
+    x -= 0.5f; y -= 0.5f;
+    float fx0 = floorf(x), fy0 = floorf(y);
+    float fx = x - fx0, fy = y - fy0;
+    int i0 = wrap_addr((int)fx0, t.width, s.address_u), i1 = wrap_addr((int)fx0 + 1, t.width, s.address_u);
+    int j0 = wrap_addr((int)fy0, t.height, s.address_v), j1 = wrap_addr((int)fy0 + 1, t.height, s.address_v);
+    const uint32_t* r0 = t.texels + (size_t)j0 * t.width;
+    const uint32_t* r1 = t.texels + (size_t)j1 * t.width;
+    uint32_t t00 = r0[i0], t10 = r0[i1], t01 = r1[i0], t11 = r1[i1];
+    float w00 = (1 - fx) * (1 - fy), w10 = fx * (1 - fy), w01 = (1 - fx) * fy, w11 = fx * fy;
+    return unpack_texel(t00, t.srgb, srgb_lut) * w00 + unpack_texel(t10, t.srgb, srgb_lut) * w10 +
+           unpack_texel(t01, t.srgb, srgb_lut) * w01 + unpack_texel(t11, t.srgb, srgb_lut) * w11;
+}
+// TransformUv + SampleTexture (Material.hlsli:68-96): (T*(R*S))*(u,v,1) has rows (c*sx, s*sy, ox), (-s*sx, c*sy, oy).
+PT_DEV vec4 sample_material_texture(const SceneRec& sc, const pt_texture_sample& a, const vec2 tc[2], unsigned& taps) {
+    vec2 uv = tc[a.tex_coord & 1];
+    float sn = sinf(a.rotation), cs = cosf(a.rotation);
+    float tu = (cs * a.scale[0]) * uv.x + (sn * a.scale[1]) * uv.y + a.offset[0];
+    float tv = (-sn * a.scale[0]) * uv.x + (cs * a.scale[1]) * uv.y + a.offset[1];
+    taps++;
+    return sample_texture2d(sc.textures[a.descriptor], sc.samplers[a.sampler], sc.srgb_lut, tu, tv);
+}
+
+// ---------------------------------------------------------------- vertex fetch (PathTracer.lib.hlsl:176-302)
+PT_DEV void fetch_indices(const SceneRec& sc, int index_descriptor, uint32_t prim, uint32_t v[3]) {   // :176-184
+    v[0] = prim * 3; v[1] = prim * 3 + 1; v[2] = prim * 3 + 2;
+    if (index_descriptor != -1) {
+        const BufferRec& b = sc.buffers[index_descriptor];
+        if (b.format == PT_FORMAT_R16_UINT) {
+            const uint16_t* p = (const uint16_t*)b.ptr;
+            v[0] = p[v[0]]; v[1] = p[v[1]]; v[2] = p[v[2]];
+        } else {
+            const uint32_t* p = (const uint32_t*)b.ptr;
+            v[0] = p[v[0]]; v[1] = p[v[1]]; v[2] = p[v[2]];
+        }
+    }
+}
+PT_DEV vec3 load_pos(const SceneRec& sc, int desc, uint32_t v) {
+    const float* p = (const float*)sc.buffers[desc].ptr + (size_t)v * 3;
+    return {p[0], p[1], p[2]};
+}
+PT_DEV vec4 fetch_vertex_color(const SceneRec& sc, int desc, const uint32_t v[3], vec3 w) {     // :229-242
+    if (desc == -1) return {1, 1, 1, 1};
+    const uint2* p = (const uint2*)sc.buffers[desc].ptr;
+    vec4 r = {0, 0, 0, 0};
+    float ww[3] = {w.x, w.y, w.z};
+    vec4 c[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        uint2 q = p[v[i]];
+        c[i] = {(float)(q.x & 0xffff) / 65535.f, (float)(q.x >> 16) / 65535.f, (float)(q.y & 0xffff) / 65535.f, (float)(q.y >> 16) / 65535.f};
+    }
+    r = c[0] * ww[0] + c[1] * ww[1] + c[2] * ww[2];
+    return r;
+}
+PT_DEV vec2 fetch_texcoord(const SceneRec& sc, int desc, const uint32_t v[3], vec3 w) {         // :244-257
+    if (desc == -1) return {0, 0};
+    const float2* p = (const float2*)sc.buffers[desc].ptr;
+    float2 a = p[v[0]], b = p[v[1]], c = p[v[2]];
+    return {w.x * a.x + w.y * b.x + w.z * c.x, w.x * a.y + w.y * b.y + w.z * c.y};
+}
+struct HitGeom {                       // VertexAttributes, PathTracer.lib.hlsl:270-278
+    vec3 position, ng, n, t, bt;
+    float tw;
+    vec4 color;
+    vec2 tc[2];
+};
+PT_DEV HitGeom get_vertex_attributes(const SceneRec& sc, const pt_mesh_instance& in, uint32_t prim, vec3 w) {   // :280-302
+    HitGeom a;
+    uint32_t v[3];
+    fetch_indices(sc, in.index_descriptor, prim, v);
+    vec3 p0 = load_pos(sc, in.position_descriptor, v[0]), p1 = load_pos(sc, in.position_descriptor, v[1]), p2 = load_pos(sc, in.position_descriptor, v[2]);
+    vec3 pos = w.x * p0 + w.y * p1 + w.z * p2;
+    vec3 ng = cross(p1 - p0, p2 - p0);                     // :196-199 un-normalised
+    vec3 n, t;
+    float tw;
+    if (in.tangent_space_descriptor != -1) {               // :201-222
+        const uint32_t* ts = (const uint32_t*)sc.buffers[in.tangent_space_descriptor].ptr;
+        vec3 n0, n1, n2, t0, t1, t2;
+        float w0, w1, w2;
+        decode_tangent_space(ts[v[0]], n0, t0, w0);
+        decode_tangent_space(ts[v[1]], n1, t1, w1);
+        decode_tangent_space(ts[v[2]], n2, t2, w2);
+        n = w.x * n0 + w.y * n1 + w.z * n2;
+        t = w.x * t0 + w.y * t1 + w.z * t2;
+        tw = w0;                                           // winding from vertex 0 only (quirk q16)
+    } else {
+        n = ng;
+        vec3 helper = v3(1, 0, 0);                         // GenerateTangent :166-174
+        if (fabsf(ng.x) > fabsf(ng.y)) helper = v3(0, 1, 0);
+        t = normalize(cross(helper, ng));
+        tw = 1;
+    }
+    a.position = mul_point(in.transform, pos);
+    a.ng = normalize(mul_dir(in.normal_transform, ng));
+    a.n = normalize(mul_dir(in.normal_transform, n));
+    a.t = normalize(mul_dir(in.transform, t));
+    a.tw = tw;
+    a.bt = tw * normalize(cross(a.n, a.t));                // :224-227
+    a.color = fetch_vertex_color(sc, in.color_descriptor, v, w);
+    a.tc[0] = fetch_texcoord(sc, in.texcoord_descriptors[0], v, w);
+    a.tc[1] = fetch_texcoord(sc, in.texcoord_descriptors[1], v, w);
+    return a;
+}
+
+// ---------------------------------------------------------------- material evaluation (Material.hlsli, PathTracer.lib.hlsl:318-381)
+struct Surface {                       // live subset of SurfaceProperties (Bsdf.hlsli:4-24)
+    vec3 albedo; float alpha, metalness, ax, ay;          // roughness_squared = (ax, ay)
+    vec3 n, at, ab; float ior;
+    vec3 spec_color; float spec_factor, clearcoat, cc_rough;
+    vec3 cc_n, sheen_color; float sheen_a, transmissive;
+};
+PT_DEV vec4 base_color(const SceneRec& sc, const pt_material& m, const vec2 tc[2], vec4 vc, unsigned& taps) {   // Material.hlsli:98-106
+    vec4 c = {m.base_color_factor[0], m.base_color_factor[1], m.base_color_factor[2], m.base_color_factor[3]};
+    c = c * vc;
+    if (m.albedo.descriptor != -1) c = c * sample_material_texture(sc, m.albedo, tc, taps);
+    return c;
+}
+PT_DEV float alpha_of(const pt_material& m, vec4 c) {                                                         // :108-117
+    if (m.alpha_mode == PT_ALPHA_MODE_BLEND) return c.w;
+    if (m.alpha_mode == PT_ALPHA_MODE_MASK) return c.w < m.alpha_cutoff ? 0.f : 1.f;
+    return 1;
+}
+PT_DEV vec3 normal_from_map(const SceneRec& sc, const pt_texture_sample& a, float scale, const vec2 tc[2], vec3 gn, vec3 t, vec3 b, unsigned& taps) {  // :119-128,199-208
+    if (a.descriptor == -1) return gn;
+    vec4 s = sample_material_texture(sc, a, tc, taps);
+    vec3 nm = v3(s.x * 2.f - 1.f, s.y * 2.f - 1.f, s.z * 2.f - 1.f);
+    nm.x *= scale; nm.y *= scale;
+    return normalize(to_world(t, b, gn, nm));
+}
+PT_DEV vec3 emissive_of(const SceneRec& sc, const pt_material& m, const vec2 tc[2], unsigned& taps) {         // :151-159
+    vec3 e = v3p(m.emissive_factor);
+    if (m.emissive.descriptor != -1) e = e * xyz(sample_material_texture(sc, m.emissive, tc, taps));
+    return e;
+}
+PT_DEV vec3 normal_adaptation(vec3 ng, vec3 ns, vec3 v) {          // PathTracer.lib.hlsl:306-316
+    vec3 r = reflect(-v, ns);
+    float rdng = dot(r, ng);
+    if (rdng < 0) return normalize(v + normalize(r - rdng * ng));
+    return ns;
+}
+PT_DEV Surface get_surface(const SceneRec& sc, uint32_t flags, const pt_material& m, const HitGeom& a, vec3 view, unsigned& taps) {
+    Surface s;
+    vec4 bc = base_color(sc, m, a.tc, a.color, taps);
+    s.albedo = xyz(bc);
+    s.alpha = alpha_of(m, bc);
+    s.n = normal_from_map(sc, m.normal, m.normal_scale, a.tc, a.n, a.t, a.bt, taps);
+    if (flags & PT_FLAG_SHADING_NORMAL_ADAPTATION) s.n = normal_adaptation(a.ng, s.n, view);
+    float metal = m.metalness_factor, rough = m.roughness_factor;                                 // Material.hlsli:130-140
+    if (m.metallic_roughness.descriptor != -1) { vec4 t = sample_material_texture(sc, m.metallic_roughness, a.tc, taps); metal *= t.z; rough *= t.y; }
+    s.metalness = metal;
+    s.ay = hmax(rough * rough, kMinRoughness);
+    // PathTracer.lib.hlsl:339,341: occlusion and the first emissive fetch are dead values; the fetches are
+    // skipped here (no visible effect) but still counted so tap counters match the reference's traffic.
+    if (m.occlusion.descriptor != -1) taps++;
+    if (m.emissive.descriptor != -1) taps++;
+    s.ior = m.ior;
+    s.spec_factor = m.specular_factor;                                                            // :161-168
+    if (m.specular.descriptor != -1) s.spec_factor *= sample_material_texture(sc, m.specular, a.tc, taps).w;
+    s.spec_color = v3p(m.specular_color_factor);                                                   // :170-177
+    if (m.specular_color.descriptor != -1) s.spec_color = s.spec_color * xyz(sample_material_texture(sc, m.specular_color, a.tc, taps));
+    s.clearcoat = m.clearcoat_factor;                                                             // :179-186
+    if (m.clearcoat.descriptor != -1) s.clearcoat *= sample_material_texture(sc, m.clearcoat, a.tc, taps).x;
+    s.cc_rough = m.clearcoat_roughness_factor;                                                    // :188-195
+    if (m.clearcoat_roughness.descriptor != -1) s.cc_rough *= sample_material_texture(sc, m.clearcoat_roughness, a.tc, taps).y;
+    s.cc_n = normal_from_map(sc, m.clearcoat_normal, m.clearcoat_normal_scale, a.tc, a.n, a.t, a.bt, taps);
+    if (flags & PT_FLAG_SHADING_NORMAL_ADAPTATION) s.cc_n = normal_adaptation(a.ng, s.cc_n, view);
+    // GetAnisotropyStrengthAndDirection (Material.hlsli:246-262)
+    float strength = m.anisotropy_strength;
+    vec3 av = v3(1, 0, 1);
+    if (m.anisotropy.descriptor != -1) {
+        vec4 t = sample_material_texture(sc, m.anisotropy, a.tc, taps);
+        av = v3(t.x * 2 - 1, t.y * 2 - 1, t.z);
+    }
+    float cr = cosf(m.anisotropy_rotation), sr = sinf(m.anisotropy_rotation);
+    vec2 adir = normalize(vec2{cr * av.x + -sr * av.y, sr * av.x + cr * av.y});
+    strength *= av.z;
+    // CalculateShadingTangentAndBitangent (Material.hlsli:264-270)
+    vec3 sb = normalize(cross(s.n, a.t));
+    vec3 st = normalize(cross(sb, s.n));
+    sb = sb * a.tw;
+    s.at = normalize(to_world(st, sb, s.n, v3(adir.x, adir.y, 0)));
+    s.ab = normalize(cross(s.at, s.n));
+    s.ax = hmax(lerpf(s.ay, 1, strength * strength), kMinRoughness);
+    s.sheen_color = v3p(m.sheen_color_factor);                                                     // :210-217
+    if (m.sheen_color.descriptor != -1) s.sheen_color = s.sheen_color * xyz(sample_material_texture(sc, m.sheen_color, a.tc, taps));
+    float sheen_rough = m.sheen_roughness_factor;                                                 // :219-226
+    if (m.sheen_roughness.descriptor != -1) sheen_rough *= sample_material_texture(sc, m.sheen_roughness, a.tc, taps).w;
+    s.sheen_a = hmax(sheen_rough * sheen_rough, kMinRoughness);
+    s.transmissive = m.transmission_factor;                                                       // :228-235
+    if (m.transmission.descriptor != -1) s.transmissive *= sample_material_texture(sc, m.transmission, a.tc, taps).x;
+    if (m.thickness.descriptor != -1) taps++;            // thickness is loaded upstream but unused (quirk q14)
+    // ClosestHit :856-861
+    s.ax = hmax(s.ax, kMinRoughness); s.ay = hmax(s.ay, kMinRoughness);
+    s.cc_rough = hmax(s.cc_rough, kMinRoughness);
+    if (flags & PT_FLAG_MATERIAL_USE_GEOMETRIC_NORMALS) { s.n = a.ng; s.cc_n = a.ng; }
+    return s;
+}
+
+// ---------------------------------------------------------------- BSDF terms (Bsdf.hlsli)
+PT_DEV float schlick(float f0, float c) { return f0 + (1 - f0) * hpow(1 - fabsf(c), 5); }                    // :39-42
+PT_DEV vec3 schlick3(vec3 f0, float c) { return f0 + (1 - f0) * hpow(1 - fabsf(c), 5); }                     // :44-47
+PT_DEV float ggx_d(float a, float ndh) {                                                                       // :50-57
+    float a2 = a * a;
+    float den = ndh * ndh * (a2 - 1) + 1;
+    den *= kPi * den;
+    return a2 * heavyside(ndh) / den;
+}
+PT_DEV float ggx_corr_v(float a, float ndl, float ndv, float hdl, float hdv) {                                 // :78-85
+    float a2 = a * a;
+    float num = 0.5f * heavyside(hdl) * heavyside(hdv);
+    float den = fabsf(ndv) * sqrtf(a2 + (1 - a2) * ndl * ndl);
+    den += fabsf(ndl) * sqrtf(a2 + (1 - a2) * ndv * ndv);
+    return num / den;
+}
+PT_DEV float specular_brdf(float a, float ndl, float ndv, float ndh, float hdl, float hdv) { return ggx_corr_v(a, ndl, ndv, hdl, hdv) * ggx_d(a, ndh); }  // :87-90
+PT_DEV float ggx_aniso_d(float ax, float ay, vec3 h) {                                                         // :93-99
+    float a2 = ax * ay;
+    vec3 f = v3(ay * h.x, ax * h.y, a2 * h.z);
+    float w2 = a2 / dot(f, f);
+    return heavyside(h.z) * a2 * w2 * w2 / kPi;
+}
+PT_DEV float aniso_specular_brdf(float ax, float ay, vec3 v, vec3 h, vec3 l) {                                 // :117-130
+    float hdv = dot(h, v), hdl = dot(h, l);
+    float num = 0.5f * heavyside(hdv) * heavyside(hdl);
+    float vv = fabsf(l.z) * length(v3(ax * v.x, ay * v.y, v.z));
+    float ll = fabsf(v.z) * length(v3(ax * l.x, ay * l.y, l.z));
+    return (num / (vv + ll)) * ggx_aniso_d(ax, ay, h);
+}
+PT_DEV float fresnel_coat_w(float weight, float ndv) {            // FresnelCoat's lerp factor, IOR 1.5 (:157-163)
+    float f0 = (1 - 1.5f) / (1 + 1.5f);
+    f0 *= f0;
+    return weight * schlick(f0, ndv);
+}
+PT_DEV float sheen_l(float alpha, float x) {                                                                   // :175-184
+    float t = (1 - alpha) * (1 - alpha);
+    float a = lerpf(21.5473f, 25.3245f, t), b = lerpf(3.82987f, 3.32435f, t), c = lerpf(0.19823f, 0.16801f, t);
+    float d = lerpf(-1.97760f, -1.27393f, t), e = lerpf(-4.32054f, -4.85967f, t);
+    return a / (1 + b * hpow(x, c)) + d * x + e;
+}
+PT_DEV float sheen_shadowing(float alpha, float c) {                                                           // :186-193
+    if (c < 0.5f) return expf(sheen_l(alpha, c));
+    return expf(2 * sheen_l(alpha, 0.5f) - sheen_l(alpha, 1 - c));
+}
+PT_DEV float sheen_brdf(float alpha, float ndl, float ndv, float ndh) {                                        // :166-173,195-203
+    float inv_r = 1 / alpha;
+    float sin2h = 1 - ndh * ndh;
+    float d = (2 + inv_r) * hpow(sin2h, inv_r * 0.5f) / (2 * kPi);
+    // SheenBrdf passes (n_dot_v, n_dot_l) into SheenVisibility(alpha, n_dot_l, n_dot_v): swapped names, same product
+    float vis = clampf(1 / ((1 + sheen_shadowing(alpha, ndv) + sheen_shadowing(alpha, ndl)) * 4 * ndv * ndl), 0, 1);
+    return d * vis;
+}
+PT_DEV float sheen_e(const float* lut, float alpha, float cos_theta) {   // Bsdf.hlsli:204-208: bilinear, clamp, 16x16
+    float x = cos_theta * 16.f - 0.5f, y = alpha * 16.f - 0.5f;
+    if (!(x == x)) x = 0;
+    if (!(y == y)) y = 0;
+    x = clampf(x, -1.f, 16.f); y = clampf(y, -1.f, 16.f);
+    float fx0 = floorf(x), fy0 = floorf(y);
+    int i0 = (int)fx0, j0 = (int)fy0;
+    float fx = x - fx0, fy = y - fy0;
+    int ia = max(i0, 0), ib = min(i0 + 1, 15), ja = max(j0, 0), jb = min(j0 + 1, 15);
+    ia = min(ia, 15); ja = min(ja, 15); ib = max(ib, 0); jb = max(jb, 0);
+    float w00 = (1 - fx) * (1 - fy), w10 = fx * (1 - fy), w01 = (1 - fx) * fy, w11 = fx * fy;
+    return lut[ja * 16 + ia] * w00 + lut[ja * 16 + ib] * w10 + lut[jb * 16 + ia] * w01 + lut[jb * 16 + ib] * w11;
+}
+PT_DEV float modulate_roughness(float a, float ior) { return clampf(lerpf(0, a, saturate(2 * (ior - 1))), kMinRoughness, 1.0f); }   // :216-220
+
+// GltfBsdf, both overloads (Bsdf.hlsli:241-325).  mode 0: overload without the flag (all terms);
+// mode 1: is_transmission == false; mode 2: is_transmission == true.
+PT_DEV vec3 gltf_bsdf(const float* lut, const Surface& s, vec3 v, vec3 l, int mode) {
+    vec3 n = s.n;
+    vec3 h = normalize(v + l);
+    vec3 vl = to_local(s.at, s.ab, n, v), hl = to_local(s.at, s.ab, n, h), ll = to_local(s.at, s.ab, n, l);
+    float hdl = dot(h, l), hdv = dot(h, v);
+    float h_dot_abs_l = dot(normalize(v3(ll.x, ll.y, fabsf(ll.z)) + vl), vl);
+    bool refl = mode != 2, trans = mode != 1;
+    float spec = refl ? saturate(ll.z) * aniso_specular_brdf(s.ax, s.ay, vl, hl, ll) : 0.f;
+    vec3 diffuse = refl ? saturate(ll.z) * (s.albedo / kPi) : v3(0);
+    vec3 transmission = v3(0);
+    if (trans) {                                           // ThinSurfaceTransmissionBtdf :222-228
+        float a = modulate_roughness(s.ay, s.ior);
+        vec3 lr = l - 2 * dot(n, l) * n;
+        vec3 hr = normalize(v + lr);
+        transmission = saturate(-ll.z) * (s.albedo * specular_brdf(a, dot(n, lr), dot(n, v), dot(n, hr), dot(hr, lr), dot(hr, v)));
+    }
+    diffuse = lerp3(diffuse, transmission, s.transmissive);
+    // FresnelMix :137-144
+    float f0s = (1 - s.ior) / (1 + s.ior);
+    vec3 f0 = v3(f0s);
+    f0 *= f0 * s.spec_color;
+    f0 = hmin(f0, v3(1));
+    vec3 fr = schlick3(f0, h_dot_abs_l);
+    vec3 dielectric = (1 - s.spec_factor * max3(fr)) * diffuse + s.spec_factor * fr * v3(spec);
+    vec3 metal = refl ? v3(spec) * schlick3(s.albedo, hdv) : v3(0);                // ConductorFresnel :146-149
+    vec3 material = lerp3(dielectric, metal, s.metalness);
+    float sa = clampf(s.sheen_a, 0.000001f, 1);
+    vec3 sheen = refl ? v3(saturate(ll.z) * sheen_brdf(sa, ll.z, vl.z, hl.z)) : v3(0);
+    float ms = max3(s.sheen_color);                                               // SheenMix :210-214
+    float scaling = hmin(1.0f - ms * sheen_e(lut, sa, vl.z), 1.0f - ms * sheen_e(lut, sa, ll.z));
+    material = s.sheen_color * sheen + material * scaling;
+    float cndv = dot(n, v), cndh = dot(n, h), cndl = dot(n, l);                    // (sic) shading normal
+    float cc = refl ? saturate(cndl) * specular_brdf(s.cc_rough, cndl, cndv, cndh, hdl, hdv) : 0.f;
+    return lerp3(material, v3(cc), fresnel_coat_w(s.clearcoat, cndv));             // FresnelCoat(1.5, ...)
+}
+
+// ---------------------------------------------------------------- sampling (Sampling.hlsli, Transforms.hlsli)
+PT_DEV vec2 uv_to_square(vec2 uv) { return {uv.x * 2 + -1, uv.y * -2 + 1}; }                                   // Transforms.hlsli:52-55
+PT_DEV vec2 square_to_uv(vec2 s) { return {(s.x - -1) * 0.5f, (s.y - 1) * -0.5f}; }                            // :57-60
+PT_DEV vec2 square_to_disk(vec2 s) {                                                                           // :83-90
+    float r = hmax(fabsf(s.x), fabsf(s.y));
+    float phi = r == 0 ? 0 : (kPi * (r + (fabsf(s.y) - fabsf(s.x))) / (4 * r));
+    return {signf(s.x) * r * cosf(phi), signf(s.y) * r * sinf(phi)};
+}
+PT_DEV vec3 square_to_sphere(vec2 s) {                                                                         // :124-136
+    float d = 1 - (fabsf(s.x) + fabsf(s.y));
+    float r = 1 - fabsf(d);
+    float phi = (r == 0) ? 0 : (kPi / 4) * ((fabsf(s.y) - fabsf(s.x)) / r + 1);
+    float f = r * sqrtf(2 - r * r);
+    return {f * signf(s.x) * cosf(phi), f * signf(s.y) * sinf(phi), signf(d) * (1 - r * r)};
+}
+PT_DEV vec2 sphere_to_square(vec3 p) {                                                                         // :138-149
+    float r = sqrtf(1 - fabsf(p.z));
+    float phi = atan2f(fabsf(p.y), fabsf(p.x));
+    float d = signf(p.z) * (1 - r);
+    float diff = r * ((4 / kPi) * phi - 1);
+    return {signf(p.x) * 0.5f * (1 - d - diff), signf(p.y) * 0.5f * (1 - d + diff)};
+}
+PT_DEV vec3 cubemap_to_direction(int face, float u, float v) {                                                 // :10-50
+    vec3 ud, vd, fd;
+    switch (face) {
+        case 0: fd = v3(1, 0, 0); ud = v3(0, 0, -1); vd = v3(0, -1, 0); break;
+        case 1: fd = v3(-1, 0, 0); ud = v3(0, 0, 1); vd = v3(0, -1, 0); break;
+        case 2: fd = v3(0, 1, 0); ud = v3(1, 0, 0); vd = v3(0, 0, 1); break;
+        case 3: fd = v3(0, -1, 0); ud = v3(1, 0, 0); vd = v3(0, 0, -1); break;
+        case 4: fd = v3(0, 0, 1); ud = v3(1, 0, 0); vd = v3(0, -1, 0); break;
+        default: fd = v3(0, 0, -1); ud = v3(-1, 0, 0); vd = v3(0, -1, 0); break;
+    }
+    u = u * 2 - 1; v = v * 2 - 1;
+    return normalize(fd + u * ud + v * vd);
+}
+PT_DEV vec3 sample_cosine_hemisphere(vec3 n, float u0, float u1) {                                             // Sampling.hlsli:26-33
+    float theta = kTau * u0;
+    float y = 2 * u1 - 1;
+    float s = sqrtf(1.0f - y * y);
+    return normalize(n + v3(s * cosf(theta), s * sinf(theta), y));
+}
+PT_DEV float cosine_hemisphere_pdf(vec3 n, vec3 v) { return saturate(dot(v, n) / kPi); }                       // :35-38
+PT_DEV vec3 sample_ggx_normal(float a, float u0, float u1) {                                                   // :41-52
+    float phi = kTau * u0;
+    float ct = sqrtf((1 - u1) / (1 + (a * a - 1) * u1));
+    float st = sqrtf(1 - ct * ct);
+    return {st * cosf(phi), st * sinf(phi), ct};
+}
+PT_DEV float ggx_normal_pdf(float a, vec3 n, vec3 h) { float ndh = dot(n, h); return ggx_d(a, ndh) * ndh; }    // :54-58
+
+// ---------------------------------------------------------------- lobe logic (PathTracer.lib.hlsl:383-667)
+struct Lobes { float alpha, clearcoat, sheen, specular, diffuse, transmission; };
+PT_DEV Lobes lobe_probabilities(const Surface& s, vec3 v) {                                                   // :535-553
+    Lobes p;
+    float remaining = 1;
+    p.alpha = 1.0f - s.alpha;
+    remaining -= p.alpha;
+    p.clearcoat = lerpf(0.f, 1.f, fresnel_coat_w(s.clearcoat, dot(s.cc_n, v)));
+    p.clearcoat *= remaining;
+    remaining -= p.clearcoat;
+    p.sheen = any_gt0(s.sheen_color) ? 0.5f : 0.0f;
+    p.sheen *= remaining;
+    remaining -= p.sheen;
+    p.specular = 0.5f;
+    p.specular *= remaining;
+    remaining -= p.specular;
+    p.transmission = s.transmissive;
+    p.transmission *= remaining;
+    remaining -= p.transmission;
+    p.diffuse = remaining;
+    return p;
+}
+PT_DEV float transmission_pdf(const Surface& s, vec3 v, vec3 l) {                                             // :489-500
+    float a = modulate_roughness(s.ay, s.ior);
+    l = l - 2 * dot(s.n, l) * s.n;
+    vec3 h = normalize(v + l);
+    float pdf = ggx_normal_pdf(a, s.n, h);
+    pdf /= 4 * dot(v, h);
+    return pdf;
+}
+PT_DEV float bsdf_pdf(const Surface& s, vec3 v, vec3 l, bool is_transmission, const Lobes& p) {               // :555-565
+    if (is_transmission) return p.transmission * transmission_pdf(s, v, l);
+    vec3 h = normalize(v + l);
+    float vdh4 = 4 * dot(v, h);
+    float cc = ggx_normal_pdf(s.cc_rough, s.cc_n, h);                                                        // ClearcoatPdf :408-416
+    cc /= vdh4;
+    float pdf = p.clearcoat * cc;
+    float cosp = cosine_hemisphere_pdf(s.n, l);
+    pdf += p.sheen * cosp;                                                                                   // SheenPdf :423-426
+    vec3 lh = to_local(s.at, s.ab, s.n, h);                                                                  // SpecularPdf :444-460
+    float sp = ggx_aniso_d(s.ax, s.ay, lh) * lh.z;
+    sp /= vdh4;
+    pdf += p.specular * sp;
+    pdf += p.diffuse * cosp;                                                                                 // DiffusePdf :467-470
+    return pdf;
+}
+PT_DEV vec3 evaluate_bsdf(uint32_t flags, const float* lut, const Surface& s, const Lobes& p, vec3 ng, vec3 v, vec3 l, float& pdf) {   // :567-593
+    if (flags & PT_FLAG_MATERIAL_DIFFUSE_WHITE) {
+        float ndl = saturate(dot(s.n, l));
+        pdf = ndl / kPi;
+        return v3(ndl / kPi);
+    }
+    if (flags & PT_FLAG_MATERIAL_MIS) {
+        bool is_transmission = (dot(ng, l) * dot(ng, v)) < 0;
+        pdf = bsdf_pdf(s, v, l, is_transmission, p);
+        return s.alpha * gltf_bsdf(lut, s, v, l, is_transmission ? 2 : 1);
+    }
+    float ndl = saturate(dot(s.n, l));
+    pdf = ndl / kPi;
+    pdf *= s.alpha;
+    return s.alpha * gltf_bsdf(lut, s, v, l, 0);
+}
+PT_DEV vec3 sample_bsdf(uint32_t flags, const float* lut, const Surface& s, const Lobes& p, vec3 u, vec3 v, vec3& l, float& pdf,
+                        bool& is_transmission, bool& use_mis) {                                             // :595-667
+    if (flags & PT_FLAG_MATERIAL_DIFFUSE_WHITE) {
+        use_mis = true; is_transmission = false;
+        l = sample_cosine_hemisphere(s.n, u.y, u.z);
+        pdf = cosine_hemisphere_pdf(s.n, l);
+        return v3(dot(s.n, l) / kPi);
+    }
+    if (flags & PT_FLAG_MATERIAL_MIS) {
+        is_transmission = false; use_mis = true;
+        // SelectBsdf :511-533
+        float x = u.x;
+        int layer;
+        if (x <= p.alpha) layer = 4;
+        else { x -= p.alpha;
+            if (x <= p.clearcoat) layer = 3;
+            else { x -= p.clearcoat;
+                if (x <= p.sheen) layer = 2;
+                else { x -= p.sheen;
+                    if (x <= p.specular) layer = 1;
+                    else { x -= p.specular; layer = (x <= p.transmission) ? 5 : 0; } } } }
+        if (layer == 4) {                                   // BSDF_LAYER_ALPHA
+            l = -v; use_mis = false; pdf = p.alpha; is_transmission = true;
+            return v3(1 - s.alpha);
+        }
+        if (layer == 0 || layer == 2) l = sample_cosine_hemisphere(s.n, u.y, u.z);          // diffuse :462-465, sheen :418-421
+        else if (layer == 1) {                              // SampleSpecular :428-442, SampleGgxAnisotropicNormal Sampling.hlsli:60-65
+            vec2 d = square_to_disk(uv_to_square({u.y, u.z}));
+            vec3 hl = v3(d.x, d.y, sqrtf(1 - d.x * d.x - d.y * d.y));
+            hl.x *= s.ax; hl.y *= s.ay;
+            hl = normalize(hl);
+            l = reflect(-v, to_world(s.at, s.ab, s.n, hl));
+        } else if (layer == 3) {                            // SampleClearcoat :394-406
+            vec3 t, b;
+            basis_simple(s.cc_n, t, b);
+            l = reflect(-v, to_world(t, b, s.cc_n, sample_ggx_normal(s.cc_rough, u.y, u.z)));
+        } else {                                            // SampleTransmission :472-487
+            float a = modulate_roughness(s.ay, s.ior);
+            vec3 h = to_world(s.at, s.ab, s.n, sample_ggx_normal(a, u.y, u.z));
+            l = reflect(-v, h);
+            l = l - 2 * dot(s.n, l) * s.n;
+            is_transmission = true;
+        }
+        pdf = bsdf_pdf(s, v, l, is_transmission, p);
+        return s.alpha * gltf_bsdf(lut, s, v, l, is_transmission ? 2 : 1);
+    }
+    if (u.x > s.alpha) {
+        l = -v; use_mis = false; pdf = (1 - s.alpha); is_transmission = true;
+        return v3(1 - s.alpha);
+    }
+    use_mis = true; is_transmission = false;
+    l = sample_cosine_hemisphere(s.n, u.y, u.z);
+    pdf = cosine_hemisphere_pdf(s.n, l);
+    pdf *= s.alpha;
+    return s.alpha * gltf_bsdf(lut, s, v, l, 0);
+}
+
+// ---------------------------------------------------------------- lights (Lights.hlsli:26-61)
+PT_DEV void light_ray(const pt_light& light, vec3 p, vec3& dir, vec3& color) {
+    bool local = light.type == PT_LIGHT_POINT || light.type == PT_LIGHT_SPOT;
+    if (local) dir = v3p(light.position) - p;
+    else dir = -v3p(light.direction);
+    color = v3p(light.color) * light.intensity;
+    if (local) {
+        float distance = length(dir);
+        float falloff = 1.0f;
+        if (light.cutoff > 0.0f) falloff = hmax(hmin(1.0f - hpow(distance / light.cutoff, 4.0f), 1.0f), 0.0f);
+        falloff /= distance * distance;
+        color *= falloff;
+    }
+    dir = normalize(dir);
+    if (light.type == PT_LIGHT_SPOT) {
+        float scale = 1.0f / hmax(0.001f, cosf(light.inner_angle) - cosf(light.outer_angle));
+        float offset = -cosf(light.outer_angle) * scale;
+        float cd = -dot(normalize(v3p(light.direction)), dir);
+        float att = saturate(cd * scale + offset);
+        att *= att;
+        color *= att;
+    }
+}
+
+// ---------------------------------------------------------------- environment (TextureCube + importance pyramid)
+PT_DEV void dir_to_face(vec3 d, int& face, float& u, float& v) {   // D3D major-axis table = inverse of cubemap_to_direction
+    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z), sc, tc, ma;
+    if (ax >= ay && ax >= az) { ma = ax; if (d.x >= 0) { face = 0; sc = -d.z; tc = -d.y; } else { face = 1; sc = d.z; tc = -d.y; } }
+    else if (ay >= az) { ma = ay; if (d.y >= 0) { face = 2; sc = d.x; tc = d.z; } else { face = 3; sc = d.x; tc = -d.z; } }
+    else { ma = az; if (d.z >= 0) { face = 4; sc = d.x; tc = -d.y; } else { face = 5; sc = -d.x; tc = -d.y; } }
+    u = 0.5f * (sc / ma + 1.0f);
+    v = 0.5f * (tc / ma + 1.0f);
+}
+PT_DEV vec3 cube_texel(const uint16_t* cube, int n, int face, int i, int j) {
+    const uint2 q = *(const uint2*)(cube + (((size_t)face * n + j) * n + i) * 4);     // 8-B RGBA16F texel
+    return {half_bits_to_float((uint16_t)(q.x & 0xffff)), half_bits_to_float((uint16_t)(q.x >> 16)), half_bits_to_float((uint16_t)(q.y & 0xffff))};
+}
+PT_DEV vec3 cube_tap(const uint16_t* cube, int n, int face, int i, int j) {
+    if (i >= 0 && i < n && j >= 0 && j < n) return cube_texel(cube, n, face, i, j);
+    // seamless edge: re-project the tap's direction onto the neighbouring face, point fetch there
+    vec3 d = cubemap_to_direction(face, ((float)i + 0.5f) / (float)n, ((float)j + 0.5f) / (float)n);
+    int f2; float u, v;
+    dir_to_face(d, f2, u, v);
+    int ii = (int)floorf(u * (float)n), jj = (int)floorf(v * (float)n);
+    ii = min(max(ii, 0), n - 1); jj = min(max(jj, 0), n - 1);
+    return cube_texel(cube, n, f2, ii, jj);
+}
+// TextureCube.SampleLevel(linear, dir, 0) (PathTracer.lib.hlsl:700,1042)
+PT_DEV vec3 sample_cube(const uint16_t* cube, int n, vec3 d) {
+    int face; float u, v;
+    dir_to_face(d, face, u, v);
+    if (!(u == u) || !(v == v)) return v3(0);
+    float x = u * (float)n - 0.5f, y = v * (float)n - 0.5f;
+    float fx0 = floorf(x), fy0 = floorf(y);
+    float fx = x - fx0, fy = y - fy0;
+    int i0 = (int)fx0, j0 = (int)fy0;
+    float w00 = (1 - fx) * (1 - fy), w10 = fx * (1 - fy), w01 = (1 - fx) * fy, w11 = fx * fy;
+    return cube_tap(cube, n, face, i0, j0) * w00 + cube_tap(cube, n, face, i0 + 1, j0) * w10 +
+           cube_tap(cube, n, face, i0, j0 + 1) * w01 + cube_tap(cube, n, face, i0 + 1, j0 + 1) * w11;
+}
+PT_DEV float imp_load(const EnvRec& e, int level, uint32_t x, uint32_t y) {
+    uint32_t n = (uint32_t)e.imp_res >> level;
+    if (x >= n || y >= n) return 0.f;
+    return e.importance[e.level_offset[level] + (size_t)y * n + x];
+}
+PT_DEV vec2 sample_importance_map(const EnvRec& e, float ux, float uy, float& pdf) {                          // Sampling.hlsli:123-163
+    uint32_t px = 0, py = 0;
+    for (int i = e.imp_levels - 2; i >= 0; i--) {
+        px <<= 1; py <<= 1;
+        uint32_t n = (uint32_t)e.imp_res >> i;
+        const float* lv = e.importance + e.level_offset[i];
+        float2 top = *(const float2*)(lv + (size_t)py * n + px);          // px is even: 8-B aligned pair
+        float2 bot = *(const float2*)(lv + (size_t)(py + 1) * n + px);
+        float ul = top.x, ur = top.y, ll = bot.x, lr = bot.y;
+        float left = ul + ll, right = ur + lr, total = left + right;
+        float prob_left = left / total;
+        if (ux < prob_left) {
+            ux /= prob_left;
+            float prob_upper = ul / left;
+            if (uy < prob_upper) uy /= prob_upper;
+            else { py++; uy = (uy - prob_upper) / (1 - prob_upper); }
+        } else {
+            px++;
+            ux = (ux - prob_left) / (1 - prob_left);
+            float prob_upper = ur / right;
+            if (uy < prob_upper) uy /= prob_upper;
+            else { py++; uy = (uy - prob_upper) / (1 - prob_upper); }
+        }
+    }
+    float w = (float)e.imp_res;
+    pdf = w * w * imp_load(e, 0, px, py) / imp_load(e, e.imp_levels - 1, 0, 0);
+    return {((float)px + ux) / w, ((float)py + uy) / w};      // both axes / width (quirk q10)
+}
+PT_DEV float importance_map_pdf(const EnvRec& e, vec2 uv) {                                                   // Sampling.hlsli:165-174, Common.hlsli:12-15
+    float total = imp_load(e, e.imp_levels - 1, 0, 0);
+    float r = (float)e.imp_res;
+    int px = f2i(floorf(uv.x * r) - .5f), py = f2i(floorf(uv.y * r) - .5f);       // UVToPixel: off by one (quirk q9)
+    float value = (px < 0 || py < 0) ? 0.f : imp_load(e, 0, (uint32_t)px, (uint32_t)py);
+    return r * r * value / total;
+}
+
+// ---------------------------------------------------------------- misc
+PT_DEV vec3 offset_ray(vec3 p, vec3 ng) {                           // PathTracer.lib.hlsl:260-268 (RT Gems ch. 6)
+    const float origin = 1.0f / 32.0f, float_scale = 1.0f / 65536.0f, int_scale = 256.0f;
+    int ox = f2i(int_scale * ng.x), oy = f2i(int_scale * ng.y), oz = f2i(int_scale * ng.z);
+    float ix = __int_as_float(__float_as_int(p.x) + (p.x < 0 ? -ox : ox));
+    float iy = __int_as_float(__float_as_int(p.y) + (p.y < 0 ? -oy : oy));
+    float iz = __int_as_float(__float_as_int(p.z) + (p.z < 0 ? -oz : oz));
+    return {fabsf(p.x) < origin ? p.x + float_scale * ng.x : ix, fabsf(p.y) < origin ? p.y + float_scale * ng.y : iy,
+            fabsf(p.z) < origin ? p.z + float_scale * ng.z : iz};
+}
+PT_DEV float luminance(vec3 c) { return dot(c, v3(0.2126f, 0.7152f, 0.0722f)); }   // Color.hlsli:4-7
+
+}  // namespace pt

@@ -1,0 +1,103 @@
+// pt_types.h -- device-side scene layout in HBM for the path-tracing kernels.
+//
+// Host PODs come from include/mipt.h (byte-identical to the reference's GPU structs).  What the
+// reference reaches through bindless descriptor indices (ResourceDescriptorHeap[i]) is reached here
+// through three small tables of raw device pointers: buffers, textures, samplers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mipt.h"
+
+namespace pt {
+
+struct BufferRec {          // one vertex / index stream
+    const void* ptr;
+    uint32_t format;        // pt_format
+    uint32_t bytes;
+};
+struct TextureRec {         // RGBA8, one mip (Gltf.cpp:1059-1060)
+    const uint32_t* texels;
+    int32_t width, height;
+    uint32_t srgb, _pad;
+};
+struct SamplerRec { int32_t address_u, address_v, min_filter, mag_filter; };
+
+// Instance table row: Instance (PathTracer.lib.hlsl:32-41) + what the TLAS instance desc carried.
+struct InstanceRec {
+    pt_mesh_instance gpu;   // 156 B
+    uint32_t mask_flags;    // bits 0-7 instance mask, bit 8 cull-disable, bit 9 force-non-opaque, bit 10 mirrored
+    uint32_t tri_offset;    // first triangle of this instance in build order
+    uint32_t tri_count;
+    uint32_t _pad[2];
+};
+static_assert(sizeof(InstanceRec) == 176, "InstanceRec");
+
+// 64-B BVH2 node: both children's boxes + child references (>=0 inner node, <0 leaf: ~triangle index).
+struct __attribute__((aligned(64))) BvhNode {
+    float lo0[3], hi0[3], lo1[3], hi1[3];
+    int32_t child0, child1;
+    uint32_t _pad[2];
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode");
+
+// 48-B triangle packet in world space: v0, e1 = v1-v0, e2 = v2-v0 + ids.
+struct __attribute__((aligned(16))) TriPacket {
+    float v0[3]; uint32_t inst;
+    float e1[3]; uint32_t prim;
+    float e2[3]; uint32_t flags;   // copy of InstanceRec::mask_flags
+};
+static_assert(sizeof(TriPacket) == 48, "TriPacket");
+
+enum : uint32_t { TF_CULL_DISABLE = 1u << 8, TF_FORCE_NON_OPAQUE = 1u << 9, TF_MIRRORED = 1u << 10 };
+
+struct EnvRec {
+    const uint16_t* cube;       // mip 0, RGBA16F, [face][y][x][4]
+    int32_t cube_n;
+    const float* importance;    // sum pyramid, level 0 first
+    uint32_t level_offset[12];  // float offset of each level
+    int32_t imp_res;            // 1024
+    int32_t imp_levels;         // 11
+};
+
+struct SceneRec {
+    const BufferRec* buffers;
+    const TextureRec* textures;
+    const SamplerRec* samplers;
+    const pt_material* materials;
+    const pt_light* lights;
+    const InstanceRec* instances;
+    const BvhNode* nodes;
+    const TriPacket* tris;
+    int32_t root;               // node index, or ~0 when the scene is a single triangle
+    uint32_t num_tris;
+    const float* sheen_e;       // 16x16
+    const float* srgb_lut;      // 256
+    EnvRec env;
+    int32_t has_env;
+};
+
+// SceneConstants (PathTracer.lib.hlsl:10-30) plus the tile shard of this rank.
+struct FrameConstants {
+    float clip_to_world[16];
+    float camera_pos[3];
+    int32_t num_of_lights;
+    uint32_t res_x, res_y, seed;
+    int32_t accumulated_frames;
+    float environment_color[3];
+    float environment_intensity;
+    int32_t debug_output;
+    uint32_t flags;
+    float max_ray_length;
+    int32_t min_bounces, max_bounces;
+    float luminance_clamp, min_rr, max_rr;
+    uint32_t tiles_x, tiles_y;       // 16x16 tiles
+    uint32_t tile_rank, tile_rank_count;
+    uint32_t my_tiles;               // tiles this rank renders
+};
+
+struct Counters {
+    unsigned long long rays_primary, rays_bounce, rays_shadow, nodes, tris, hits, taps, stack_overflow;
+};
+
+}  // namespace pt

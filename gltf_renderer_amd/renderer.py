@@ -1,0 +1,222 @@
+"""ctypes binding of libmipt.so (include/mipt.h).  No CPU fallback: if the HIP library is missing or
+its symbols do not match the header, importing the Renderer fails loudly.
+
+PyTorch is used only as plumbing: the caller-owned output image is a CUDA(HIP) tensor and the
+library enqueues on torch's current stream, so torch.distributed (RCCL) can reduce the image.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmipt.so")
+
+# every symbol include/mipt.h declares
+EXPORTS = ["pt_abi_version", "pt_create", "pt_destroy", "pt_last_error", "pt_buffer_create", "pt_buffer_update", "pt_buffer_read",
+           "pt_texture_create", "pt_sampler_create", "pt_scene_set_materials", "pt_scene_set_lights", "pt_scene_set_instances",
+           "pt_env_create", "pt_env_read", "pt_build_accel", "pt_skin_run", "pt_trace", "pt_set_bounce_limit", "pt_enable_counters",
+           "pt_get_stats", "pt_readback", "pt_tonemap"]
+
+
+class MiptError(RuntimeError):
+    pass
+
+
+_LIB = None
+
+
+def load_library():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise MiptError("libmipt.so not found at %s: build it with `make -C gltf_renderer_amd/csrc` "
+                        "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    missing = [s for s in EXPORTS if not hasattr(L, s)]
+    if missing:
+        raise MiptError("libmipt.so lacks symbols declared in include/mipt.h: %s" % missing)
+    if L.pt_abi_version() != 1:
+        raise MiptError("libmipt.so ABI version mismatch")
+    vp, ci = C.c_void_p, C.c_int
+    L.pt_create.argtypes = [ci, vp, vp, C.POINTER(vp)]
+    L.pt_destroy.argtypes = [vp]
+    L.pt_destroy.restype = None
+    L.pt_last_error.argtypes = [vp]
+    L.pt_last_error.restype = C.c_char_p
+    L.pt_buffer_create.argtypes = [vp, vp, C.c_size_t, ci, C.POINTER(ci)]
+    L.pt_buffer_update.argtypes = [vp, ci, vp, C.c_size_t]
+    L.pt_buffer_read.argtypes = [vp, ci, vp, C.c_size_t]
+    L.pt_texture_create.argtypes = [vp, vp, ci, ci, ci, C.POINTER(ci)]
+    L.pt_sampler_create.argtypes = [vp, vp, C.POINTER(ci)]
+    L.pt_scene_set_materials.argtypes = [vp, vp, ci]
+    L.pt_scene_set_lights.argtypes = [vp, vp, ci]
+    L.pt_scene_set_instances.argtypes = [vp, vp, ci]
+    L.pt_env_create.argtypes = [vp, vp, ci, ci, C.POINTER(ci)]
+    L.pt_env_read.argtypes = [vp, ci, C.POINTER(ci), vp, vp]
+    L.pt_build_accel.argtypes = [vp]
+    L.pt_skin_run.argtypes = [vp, vp, vp, ci]
+    L.pt_trace.argtypes = [vp, vp, vp]
+    L.pt_set_bounce_limit.argtypes = [vp, ci]
+    L.pt_enable_counters.argtypes = [vp, ci]
+    L.pt_get_stats.argtypes = [vp, vp]
+    L.pt_readback.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp]
+    L.pt_tonemap.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp]
+    _LIB = L
+    return L
+
+
+def sheen_lut():
+    return np.fromfile(os.path.join(_HERE, "data", "sheen_e_16x16.f32"), dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Renderer:
+    """Host mirror of the reference's hot-path objects behind one context:
+    Pathtracer::{Init, PathtraceScene, Shutdown} (Source/Pathtracer.h:104-106),
+    GpuSkin::{Create, Run} (Source/GpuSkin.h:17-19), EnvironmentMap::CreateEnvironmentMap."""
+
+    def __init__(self, device=0, stream=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise MiptError("no HIP device visible: the path tracer runs on MI355X only (no CPU fallback)")
+        self.torch = torch
+        self.L = load_library()
+        self.device = device
+        torch.cuda.set_device(device)
+        self.stream = torch.cuda.current_stream(device).cuda_stream if stream is None else stream
+        lut = sheen_lut()
+        h = C.c_void_p()
+        rc = self.L.pt_create(device, C.c_void_p(self.stream), _p(lut), C.byref(h))
+        if rc != 0:
+            raise MiptError("pt_create failed: %d" % rc)
+        self.h = h
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MiptError("%d: %s" % (rc, self.L.pt_last_error(self.h).decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- resources
+    def buffer_create(self, data, fmt, nbytes=None):
+        out = C.c_int()
+        if data is None:
+            self._check(self.L.pt_buffer_create(self.h, None, nbytes, fmt, C.byref(out)))
+        else:
+            a = np.ascontiguousarray(data)
+            self._check(self.L.pt_buffer_create(self.h, _p(a), a.nbytes, fmt, C.byref(out)))
+        return out.value
+
+    def buffer_update(self, handle, data):
+        a = np.ascontiguousarray(data)
+        self._check(self.L.pt_buffer_update(self.h, handle, _p(a), a.nbytes))
+
+    def buffer_read(self, handle, dtype, count):
+        out = np.zeros(count, dtype)
+        self._check(self.L.pt_buffer_read(self.h, handle, _p(out), out.nbytes))
+        return out
+
+    def texture_create(self, rgba8, srgb):
+        a = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        h, w = a.shape[:2]
+        out = C.c_int()
+        self._check(self.L.pt_texture_create(self.h, _p(a), w, h, int(bool(srgb)), C.byref(out)))
+        return out.value
+
+    def sampler_create(self, address_u, address_v, min_filter, mag_filter):
+        d = abi.PtSamplerDesc(address_u, address_v, min_filter, mag_filter)
+        out = C.c_int()
+        self._check(self.L.pt_sampler_create(self.h, C.byref(d), C.byref(out)))
+        return out.value
+
+    def set_materials(self, materials):
+        arr = (abi.PtMaterial * len(materials))(*materials)
+        self._check(self.L.pt_scene_set_materials(self.h, C.byref(arr), len(materials)))
+
+    def set_lights(self, lights):
+        if len(lights) == 0:
+            self._check(self.L.pt_scene_set_lights(self.h, None, 0))
+            return
+        arr = (abi.PtLight * len(lights))(*lights)
+        self._check(self.L.pt_scene_set_lights(self.h, C.byref(arr), len(lights)))
+
+    def set_instances(self, instances):
+        arr = (abi.PtInstanceDesc * len(instances))(*instances)
+        self._check(self.L.pt_scene_set_instances(self.h, C.byref(arr), len(instances)))
+
+    def env_create(self, equirect_rgb32f):
+        a = np.ascontiguousarray(equirect_rgb32f, dtype=np.float32)
+        h, w = a.shape[:2]
+        out = C.c_int()
+        self._check(self.L.pt_env_create(self.h, _p(a), w, h, C.byref(out)))
+        return out.value
+
+    def env_read(self, env):
+        n = C.c_int()
+        self._check(self.L.pt_env_read(self.h, env, C.byref(n), None, None))
+        cube = np.zeros((6, n.value, n.value, 4), np.uint16)
+        pyr = np.zeros(sum((1024 >> i) ** 2 for i in range(11)), np.float32)
+        self._check(self.L.pt_env_read(self.h, env, C.byref(n), _p(cube), _p(pyr)))
+        return n.value, cube, pyr
+
+    def set_bounce_limit(self, limit):
+        self._check(self.L.pt_set_bounce_limit(self.h, limit))
+
+    def enable_counters(self, on):
+        self._check(self.L.pt_enable_counters(self.h, int(on)))
+
+    def build_accel(self):
+        self._check(self.L.pt_build_accel(self.h))
+
+    def skin_run(self, params, bones):
+        if bones is None or len(bones) == 0:
+            self._check(self.L.pt_skin_run(self.h, C.byref(params), None, 0))
+        else:
+            arr = (abi.PtBone * len(bones))(*bones)
+            self._check(self.L.pt_skin_run(self.h, C.byref(params), C.byref(arr), len(bones)))
+
+    # ---- rendering
+    def create_output(self, width, height):
+        return self.torch.zeros((height, width, 4), dtype=self.torch.float32, device="cuda:%d" % self.device)
+
+    def trace(self, settings, params, output):
+        """output: torch float32 CUDA tensor (H, W, 4), the caller-owned accumulation target."""
+        assert output.is_cuda and output.is_contiguous() and output.dtype == self.torch.float32
+        assert tuple(output.shape) == (params.height, params.width, 4)
+        params.output = output.data_ptr()
+        self._check(self.L.pt_trace(self.h, C.byref(settings), C.byref(params)))
+
+    def stats(self):
+        s = abi.PtStats()
+        self._check(self.L.pt_get_stats(self.h, C.byref(s)))
+        return s
+
+    def readback(self, output):
+        h, w = output.shape[:2]
+        out = np.zeros((h, w, 4), np.float32)
+        self._check(self.L.pt_readback(self.h, C.c_void_p(output.data_ptr()), w, h, _p(out)))
+        return out
+
+    def tonemap(self, output, config=None, want_rgba8=False):
+        cfg = config or abi.PtTonemapConfig.default()
+        h, w = output.shape[:2]
+        rgb = np.zeros((h, w, 3), np.float32)
+        q = np.zeros((h, w, 4), np.uint8) if want_rgba8 else None
+        self._check(self.L.pt_tonemap(self.h, C.byref(cfg), C.c_void_p(output.data_ptr()), w, h, _p(rgb), _p(q) if want_rgba8 else None))
+        return (rgb, q) if want_rgba8 else rgb
