@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s + ms/frame of the path-tracing hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched under
+torch.distributed.run, one rank per GPU.  A "step" = one pt_trace of the whole frame (1 sample per
+pixel, BASELINE.json metric) on the Sponza-class stand-in (configs[2]: 1920x1080, 8 bounces + RR,
+punctual lights + env MIS).  With N ranks the frame is sharded by 16x16 pixel tile (tile t -> rank
+t % N), every rank renders its tiles into a zeroed full-size image and ONE RCCL reduce(sum) to rank 0
+assembles the frame (tiles are disjoint, so sum = gather).  Total work is fixed -> "strong" scaling.
+
+Timed region: inputs (scene, BVH, textures, env maps) are resident in HBM; K steps bracketed by
+barrier + torch.cuda.synchronize on both sides; time = max over ranks.  value = rays traced by all
+ranks in the K steps / that time.  Rays are counted by the kernel itself (every traversal started).
+
+Extra objects on the JSON line:
+  roofline     - dominant kernel pt_megakernel: algorithmic bytes per launch (counted by an untimed
+                 instrumented replay of the same K frames: nodes*64 + tris*48 + hits*S_hit + taps*16
+                 + env loads + 32 B/pixel) / mean kernel time measured live with HIP events on the
+                 launch stream; peak = 8 TB/s HBM; traffic = PMC-measured HBM bytes per launch from
+                 profiles/ (same command), or null.
+  cpu_baseline - the CPU oracle (kind "port": the reference has no CPU tracer) on a bounded sample of
+                 the same workload, all host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="sponza", choices=["sponza", "helmet", "grid", "figure", "test"])
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--save-image", default="")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+    from gltf_renderer_amd import scenes, abi
+    from gltf_renderer_amd.renderer import Renderer
+
+    t_setup = time.time()
+    if args.config == "sponza":
+        s = scenes.sponza_class()
+    elif args.config == "helmet":
+        s = scenes.helmet_class()
+    elif args.config == "grid":
+        s = scenes.material_grid()
+    elif args.config == "figure":
+        s = scenes.skinned_figure()
+    else:
+        s = scenes.test_scene(512, 256)
+    if args.width and args.height:
+        s.width, s.height = args.width, args.height
+
+    r = Renderer(device=local_rank)
+    h = s.upload(r)
+    r.build_accel()
+    settings = s.settings
+    out = r.create_output(s.width, s.height)
+    torch.cuda.synchronize()
+    accel_ms = r.stats().accel_ms
+    t_setup = time.time() - t_setup
+
+    def step(frame):
+        if world > 1:
+            out.zero_()
+            settings.reset = 1          # each step is a fresh 1-spp frame when sharded (the reduce sums disjoint tiles)
+        p = s.execute_params(frame=frame, tile_rank=rank, tile_rank_count=world, env_handle=h["env"])
+        r.trace(settings, p, out)
+        if world > 1:
+            dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for f in range(args.warmup):
+        step(f)
+    sync_all()
+    r.reset_stats()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    sync_all()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        frame = args.warmup + k
+        if world > 1:
+            out.zero_()
+            settings.reset = 1
+        p = s.execute_params(frame=frame, tile_rank=rank, tile_rank_count=world, env_handle=h["env"])
+        ev[k][0].record()
+        r.trace(settings, p, out)
+        ev[k][1].record()
+        if world > 1:
+            dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    st = r.stats()
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    rays_local = int(st.rays)
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    ry = torch.tensor([rays_local], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ry, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    rays_total = float(ry.item())
+
+    result = None
+    if rank == 0:
+        mrays = rays_total / elapsed / 1e6
+        result = {
+            "metric": "Mrays/sec + ms/frame @1920x1080, 8-bounce, 1/2/4/8 MI355X",
+            "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1000.0, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s %dx%d 1spp/step, max_bounces %d (limit %d), min_bounces %d, RR %.1f-%.1f, %d triangles / %d instances / %d textures / %d lights, env-map MIS, flags 0x%x"
+                       % (s.name, s.width, s.height, settings.max_bounces, s.bounce_limit, settings.min_bounces,
+                          settings.min_russian_roulette_continue_prob, settings.max_russian_roulette_continue_prob, s.triangles,
+                          len(s.instances), len(s.textures), len(s.lights), settings.flags),
+                       "parallelism": "tile-shard x%d + 1 RCCL reduce/frame" % world if world > 1 else "single GPU",
+                       "rays_per_frame": round(rays_total / args.steps, 1), "bvh_build_ms": round(accel_ms, 3), "scene_setup_s": round(t_setup, 1)},
+        }
+
+    # ---- roofline: instrumented untimed replay of the same frames (rank 0, N = 1 only)
+    if rank == 0 and world == 1 and not args.no_roofline:
+        r.enable_counters(True)
+        settings2 = abi.PtSettings.from_buffer_copy(bytes(settings))
+        out2 = r.create_output(s.width, s.height)
+        torch.cuda.synchronize()
+        r.reset_stats()
+        for k in range(args.steps):
+            p = s.execute_params(frame=args.warmup + k, env_handle=h["env"])
+            r.trace(settings2, p, out2)
+        c = r.stats()
+        r.enable_counters(False)
+        n = float(args.steps)
+        env_mis = bool(settings.flags & abi.FLAG_ENVIRONMENT_MIS) and bool(settings.flags & abi.FLAG_ENVIRONMENT_MAP)
+        # bytes/ray = N_node*64 + N_tri*48 + [closest hits] S_hit + 32/R per pixel-sample
+        s_hit = 12 + 3 * (12 + 4 + 8) + 176 + 640            # indices + 3 vertices + instance row + material
+        alg = (c.nodes_visited * 64 + c.tris_tested * 48 + c.closest_hits * s_hit + c.texture_taps * 16
+               + (c.closest_hits * 40 * 4 if env_mis else 0) + (c.rays_primary + c.rays_bounce - c.closest_hits) * 64) / n + s.width * s.height * 32
+        mean_ms = sum(kernel_ms) / len(kernel_ms)
+        achieved = alg / (mean_ms * 1e-3) / 1e9
+        traffic = None
+        pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pj):
+            try:
+                traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result["roofline"] = {"bound": "hbm", "kernel": "pt_megakernel", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                              "frac": round(achieved / 8000.0, 5), "traffic": traffic,
+                              "algorithmic_bytes_per_launch": round(alg), "kernel_ms_mean": round(mean_ms, 4),
+                              "nodes_per_ray": round(c.nodes_visited / max(c.rays, 1), 2), "tris_per_ray": round(c.tris_tested / max(c.rays, 1), 2),
+                              "rays_replay": int(c.rays)}
+
+    # ---- CPU baseline: oracle (port) on a bounded sample of the same workload
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle
+        cores = os.cpu_count() or 1
+        o = pyoracle.Oracle()
+        n_env, cube, pyr = r.env_read(h["env"]) if h["env"] is not None else (None, None, None)
+        ho = s.upload(o, env_raw=(n_env, cube, pyr) if n_env else None)
+        o.build_accel()
+        acc_ms, _ = o.timing()
+        sw, sh = s.width, s.height
+        s.width, s.height = max(sw // 8, 16), max(sh // 8, 16)       # 240x135 sample of the 1080p frame: same camera, same scene
+        img = np.zeros((s.height, s.width, 4), np.float32)
+        o.counters()
+        t1 = time.perf_counter()
+        frames = 0
+        while time.perf_counter() - t1 < 10.0 and frames < 64:
+            o.trace(settings, s.execute_params(frame=args.warmup + frames, env_handle=ho["env"]), img, nthreads=cores)
+            frames += 1
+        dt = time.perf_counter() - t1
+        cc = o.counters()
+        s.width, s.height = sw, sh
+        result["cpu_baseline"] = {"value": round(cc["rays"] / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+                                  "sample": "%d frames of the same scene/camera/settings at %dx%d (1/64 of the pixels), oracle LBVH build %.0f ms (1 thread)"
+                                  % (frames, max(sw // 8, 16), max(sh // 8, 16), acc_ms)}
+
+    if rank == 0:
+        if args.save_image:
+            from PIL import Image
+            rgb, q = r.tonemap(out, want_rgba8=True)
+            Image.fromarray(q[..., :3]).save(args.save_image)
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

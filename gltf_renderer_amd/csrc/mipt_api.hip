@@ -231,7 +231,6 @@ public:
             uint32_t ntiles = fc.tiles_x * fc.tiles_y;
             fc.my_tiles = ntiles > fc.tile_rank ? (ntiles - fc.tile_rank + fc.tile_rank_count - 1) / fc.tile_rank_count : 0;
 
-            HIPOK(hipMemsetAsync(ctx->d_counters, 0, sizeof(Counters), ctx->stream));
             HIPOK(hipEventRecord(ctx->ev_trace[0], ctx->stream));
             launch_megakernel(sc, fc, (float4*)ep->output, ctx->d_counters, ctx->counters_enabled, ctx->stream);   // :344-353
             HIPOK(hipGetLastError());
@@ -549,6 +548,12 @@ int pt_set_bounce_limit(pt_ctx* ctx, int limit) {
 int pt_enable_counters(pt_ctx* ctx, int enable) {
     if (!ctx) return PT_ERR_INVALID_ARGUMENT;
     ctx->counters_enabled = enable != 0;
+    return PT_OK;
+}
+
+int pt_reset_stats(pt_ctx* ctx) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    HIPOK(hipMemsetAsync(ctx->d_counters, 0, sizeof(Counters), ctx->stream));
     return PT_OK;
 }
 

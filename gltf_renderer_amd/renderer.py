@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libmipt.so")
 EXPORTS = ["pt_abi_version", "pt_create", "pt_destroy", "pt_last_error", "pt_buffer_create", "pt_buffer_update", "pt_buffer_read",
            "pt_texture_create", "pt_sampler_create", "pt_scene_set_materials", "pt_scene_set_lights", "pt_scene_set_instances",
            "pt_env_create", "pt_env_read", "pt_build_accel", "pt_skin_run", "pt_trace", "pt_set_bounce_limit", "pt_enable_counters",
-           "pt_get_stats", "pt_readback", "pt_tonemap"]
+           "pt_get_stats", "pt_reset_stats", "pt_readback", "pt_tonemap"]
 
 
 class MiptError(RuntimeError):
@@ -63,6 +63,7 @@ def load_library():
     L.pt_set_bounce_limit.argtypes = [vp, ci]
     L.pt_enable_counters.argtypes = [vp, ci]
     L.pt_get_stats.argtypes = [vp, vp]
+    L.pt_reset_stats.argtypes = [vp]
     L.pt_readback.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp]
     L.pt_tonemap.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp]
     _LIB = L
@@ -201,6 +202,9 @@ class Renderer:
         assert tuple(output.shape) == (params.height, params.width, 4)
         params.output = output.data_ptr()
         self._check(self.L.pt_trace(self.h, C.byref(settings), C.byref(params)))
+
+    def reset_stats(self):
+        self._check(self.L.pt_reset_stats(self.h))
 
     def stats(self):
         s = abi.PtStats()

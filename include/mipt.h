@@ -302,7 +302,7 @@ typedef struct pt_tonemap_config {
 
 /* ---- counters ------------------------------------------------------------------------------ */
 typedef struct pt_stats {
-    uint64_t rays;              /* traversals started by the last pt_trace (all kinds) */
+    uint64_t rays;              /* traversals started since pt_reset_stats (all kinds) */
     uint64_t rays_primary, rays_bounce, rays_shadow;
     uint64_t nodes_visited;     /* 64-B BVH nodes fetched (0 unless counters enabled) */
     uint64_t tris_tested;       /* 48-B triangle packets fetched (0 unless counters enabled) */
@@ -363,7 +363,10 @@ int pt_skin_run(pt_ctx* ctx, const pt_skin_params* params, const pt_bone* bones,
 int pt_trace(pt_ctx* ctx, const pt_settings* settings, const pt_execute_params* params);
 int pt_set_bounce_limit(pt_ctx* ctx, int limit);      /* default PT_REFERENCE_MAX_BOUNCES */
 int pt_enable_counters(pt_ctx* ctx, int enable);      /* node / triangle / tap counters (slower) */
+/* Counters accumulate over pt_trace calls since the last pt_reset_stats; the *_ms fields are the
+ * hipEvent times of the most recent call of each kind. */
 int pt_get_stats(pt_ctx* ctx, pt_stats* out);
+int pt_reset_stats(pt_ctx* ctx);
 
 /* Absent upstream (the reference only presents to a swapchain): offline output. */
 int pt_readback(pt_ctx* ctx, const void* device_rgba32f, uint32_t width, uint32_t height, float* host_rgba32f);

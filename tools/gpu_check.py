@@ -37,10 +37,12 @@ st = abi.PtSettings.from_buffer_copy(bytes(s.settings))
 og = r.create_output(s.width, s.height)
 b = np.zeros((s.height, s.width, 4), np.float32)
 cg = {"rays": 0}
+o.counters()
+r.reset_stats()
 t0 = time.time()
 for f in range(spp):
     r.trace(st, s.execute_params(f, env_handle=hg["env"]), og)
-    stt = r.stats(); cg["rays"] += stt.rays
+stt = r.stats(); cg["rays"] = stt.rays
 tg = time.time() - t0
 for f in range(spp):
     o.trace(st, s.execute_params(f, env_handle=ho["env"]), b)
