@@ -352,7 +352,7 @@ def helmet_class(width=1920, height=1080, subdiv=6, tex=2048, seed=2):
 
 
 # ---- config 3: "Sponza-class" --------------------------------------------------------------------------
-def sponza_class(width=1920, height=1080, tex=1024, detail=1.06, seed=3, n_textures=40):
+def sponza_class(width=1920, height=1080, tex=1024, detail=1.09, seed=3, n_textures=40):
     """BASELINE config 3 stand-in for Sponza: an atrium, ~262 k triangles in ~100 primitives (tessellated
     floor, two storeys of box columns with arches, walls, ceiling beams, hanging cloth quads), 25
     materials, ~40 1024^2 textures, 10 MASK-mode foliage quads, 4 point + 1 spot + 1 directional light,
@@ -389,7 +389,10 @@ def sponza_class(width=1920, height=1080, tex=1024, detail=1.06, seed=3, n_textu
     nm_ = lambda: mats[next(mi) % len(mats)]
     # floor, ceiling, walls  (6 primitives)
     s.add_mesh(meshgen.grid(d(160), d(64), (-L / 2, -W / 2, 0), (L, 0, 0), (0, W, 0), (12, 5)), None, nm_())
-    s.add_mesh(meshgen.grid(d(64), d(160), (-L / 2, -W / 2, H), (0, W, 0), (L, 0, 0), (5, 12)), None, nm_())
+    # the atrium is open to the sky like Sponza's: only the two gallery roofs are covered.  (Punctual-light shadow
+    # rays run 1000 units past the light, quirk q3, so in a closed room no punctual light would ever be visible.)
+    s.add_mesh(meshgen.grid(d(20), d(160), (-L / 2, -W / 2, H), (0, 2.6, 0), (L, 0, 0), (2, 12)), None, nm_())
+    s.add_mesh(meshgen.grid(d(20), d(160), (-L / 2, W / 2 - 2.6, H), (0, 2.6, 0), (L, 0, 0), (2, 12)), None, nm_())
     s.add_mesh(meshgen.grid(d(160), d(80), (-L / 2, W / 2, 0), (L, 0, 0), (0, 0, H), (12, 6)), None, nm_())
     s.add_mesh(meshgen.grid(d(80), d(160), (-L / 2, -W / 2, 0), (0, 0, H), (L, 0, 0), (6, 12)), None, nm_())
     s.add_mesh(meshgen.grid(d(80), d(64), (-L / 2, -W / 2, 0), (0, W, 0), (0, 0, H), (5, 6)), None, nm_())

@@ -262,6 +262,14 @@ static void build_lbvh(Bvh& bvh) {
 
 // ------------------------------------------------------------------------------------------------
 struct Counters { std::atomic<uint64_t> primary{0}, bounce{0}, shadow{0}, nodes{0}, tris{0}, hits{0}, taps{0}; };
+// per-thread tallies, merged into Oracle::counters when a worker finishes (no shared cache line in the hot loop)
+struct Tally { uint64_t primary = 0, bounce = 0, shadow = 0, nodes = 0, tris = 0, hits = 0, taps = 0; };
+static thread_local Tally t_tally;
+static void merge_tally(Counters& c) {
+    c.primary += t_tally.primary; c.bounce += t_tally.bounce; c.shadow += t_tally.shadow; c.nodes += t_tally.nodes;
+    c.tris += t_tally.tris; c.hits += t_tally.hits; c.taps += t_tally.taps;
+    t_tally = Tally();
+}
 
 struct Oracle {
     SheenLut lut;
@@ -363,7 +371,7 @@ static inline float2 TransformUv(const TextureAddress& a, float2 uv) {          
 }
 static float4 SampleTexture(Oracle& o, const TextureAddress& a, const float2 tc[2]) {   // :90-96
     float2 uv = TransformUv(a, tc[a.tex_coord]);
-    o.counters.taps.fetch_add(1, std::memory_order_relaxed);
+    t_tally.taps++;
     return SampleLevel0(o.textures[a.descriptor], o.samplers[a.sampler_index], uv);
 }
 static float4 GetBaseColor(Oracle& o, const Material& m, const float2 tc[2], float4 vc) {   // :98-106
@@ -607,8 +615,8 @@ struct Tracer {
                 else { if (sp == 0) break; cur = stack[--sp]; }
             }
         }
-        o.counters.nodes.fetch_add(nn, std::memory_order_relaxed);
-        o.counters.tris.fetch_add(nt, std::memory_order_relaxed);
+        t_tally.nodes += nn;
+        t_tally.tris += nt;
         return committed;
     }
 
@@ -623,7 +631,7 @@ struct Tracer {
         float transmission = 0.0f;
         if (alpha_shadow) { transmission = 1.0f; rf |= RAY_FLAG_FORCE_NON_OPAQUE; }
         else rf |= RAY_FLAG_ACCEPT_FIRST_HIT_AND_END_SEARCH;
-        o.counters.shadow.fetch_add(1, std::memory_order_relaxed);
+        t_tally.shadow++;
         Hit h;
         bool hit = traverse(ray, rf, 0xff, 1, h, transmission);
         if (!hit) transmission = 1.0f;                     // ShadowMiss :1081-1085
@@ -651,13 +659,13 @@ struct Tracer {
         const uint32_t rf = (sc.flags & F_CULL_BACKFACE) ? RAY_FLAG_CULL_FRONT_FACING_TRIANGLES : 0;   // (sic) quirk q2
         RayDesc ray = {origin, 0, direction, sc.max_ray_length};
         Payload p = {throughput, bsdf_pdf, F3(0), use_mis ? (uint32_t)PAYLOAD_FLAG_MIS : 0u, bounce + 1, seed};
-        o.counters.bounce.fetch_add(1, std::memory_order_relaxed);
+        t_tally.bounce++;
         TraceRay(rf, mask, ray, p);
         return p.color;
     }
     // ClosestHit, :788-1007
     void ClosestHit(Payload& payload, const RayDesc& ray, const Hit& h) {
-        o.counters.hits.fetch_add(1, std::memory_order_relaxed);
+        t_tally.hits++;
         const Tri& tri = o.bvh.tris[h.tri];
         float3 bw = {1 - h.u - h.v, h.u, h.v};                                     // :150-153
         const Instance& instance = o.instances[tri.inst].gpu;
@@ -784,7 +792,7 @@ struct Tracer {
         float3 origin = xyz(start) / start.w;
         float3 dir = xyz(end) / end.w - origin;
         RayDesc ray = {origin, 0, normalize(dir), length(dir)};
-        o.counters.primary.fetch_add(1, std::memory_order_relaxed);
+        t_tally.primary++;
         TraceRay(rf, 0xff, ray, payload);
         if (any_nan(payload.color)) payload.color = (sc.flags & F_SHOW_NAN) ? float3{1, 0, 0} : F3(0);
         if (any_inf(payload.color)) payload.color = (sc.flags & F_SHOW_INF) ? float3{1, 0, 0} : F3(0);
@@ -902,6 +910,7 @@ static void pathtrace_scene(Oracle& o, const Settings& s, const ExecuteParams& e
                         tr.RayGeneration((float*)ep.output);
                     }
             }
+            merge_tally(o.counters);
         };
         if (nthreads <= 1) worker();
         else {
@@ -1233,6 +1242,7 @@ void orc_intersect(void* h, const float* origin, const float* dir, float tmin, f
     RayDesc r = {{origin[0], origin[1], origin[2]}, tmin, {dir[0], dir[1], dir[2]}, tmax};
     Hit hit; float dummy = 0;
     bool got = tr.traverse(r, ray_flags, 0xff, 0, hit, dummy);
+    merge_tally(o->counters);
     out7[0] = got ? 1.f : 0.f;
     if (got) { const Tri& t = o->bvh.tris[hit.tri]; out7[1] = hit.t; out7[2] = hit.u; out7[3] = hit.v; out7[4] = (float)t.inst; out7[5] = (float)t.prim; out7[6] = hit.front ? 1.f : 0.f; }
 }
