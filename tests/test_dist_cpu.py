@@ -1,0 +1,66 @@
+"""Multi-rank tile sharding on CPU: world_size 2 over gloo.  Each rank renders its tiles (tile t belongs to rank
+t % N) into a zeroed full-size image and one reduce(sum) to rank 0 assembles the frame.
+The compute on the CPU is the oracle (tests may use it); the sharding / reduce logic is what is under test
+and is the same code path bench.py runs over RCCL."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gltf_renderer_amd import abi, scenes
+    from gltf_renderer_amd.sharding import my_tile_count, reduce_frame
+    from oracle import pyoracle
+    s = scenes.test_scene(40, 16)
+    st = abi.PtSettings.from_buffer_copy(bytes(s.settings)); st.flags &= ~abi.FLAG_ACCUMULATE
+    o = pyoracle.Oracle(); h = s.upload(o)
+    img = np.zeros((s.height, s.width, 4), np.float32)
+    o.trace(st, s.execute_params(frame=3, env_handle=h["env"], tile_rank=rank, tile_rank_count=world), img, nthreads=1)
+    touched = int((img[..., 3] != 0).sum())
+    t = torch.from_numpy(img)
+    reduce_frame(t, world)
+    counts = torch.tensor([touched, my_tile_count(s.width, s.height, rank, world)])
+    dist.all_reduce(counts)
+    if rank == 0:
+        np.save(os.path.join(tmp, "sharded.npy"), t.numpy())
+        np.save(os.path.join(tmp, "counts.npy"), counts.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_tile_sharding_equals_single_rank(tmp_path, oracle_lib):
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    from gltf_renderer_amd import abi, scenes
+    s = scenes.test_scene(40, 16)
+    st = abi.PtSettings.from_buffer_copy(bytes(s.settings)); st.flags &= ~abi.FLAG_ACCUMULATE
+    o = oracle_lib.Oracle(); h = s.upload(o)
+    full = np.zeros((s.height, s.width, 4), np.float32)
+    o.trace(st, s.execute_params(frame=3, env_handle=h["env"]), full, nthreads=1)
+    sharded = np.load(tmp_path / "sharded.npy")
+    assert np.array_equal(sharded, full)                    # bit for bit
+    counts = np.load(tmp_path / "counts.npy")
+    assert counts[0] == 40 * 40 and counts[1] == 9          # every pixel rendered exactly once; 3x3 tiles
+
+
+def test_tile_partition_is_exact():
+    from gltf_renderer_amd.sharding import my_tile_count, tile_owner
+    for (w, h) in ((1920, 1080), (3840, 2160), (50, 17), (16, 16), (1, 1)):
+        tiles = ((w + 15) // 16) * ((h + 15) // 16)
+        for n in (1, 2, 3, 4, 8):
+            assert sum(my_tile_count(w, h, r, n) for r in range(n)) == tiles
+            owners = [tile_owner(t, n) for t in range(tiles)]
+            assert all(0 <= o < n for o in owners)
+            for r in range(n):
+                assert owners.count(r) == my_tile_count(w, h, r, n)
