@@ -83,8 +83,11 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(SceneRec sc, FrameConsta
             if (!got) transmission = 1.0f;                                                          // ShadowMiss :1081-1085
         }
 
-        if (kind == KIND_SHADOW_ENV) { L += pend_env * transmission; }
-        else if (kind == KIND_SHADOW_LIGHT) { L += pend_light * transmission; }
+        // The reference multiplies the light colour by the shadow transmission BEFORE `if (any(color > 0))` and never
+        // evaluates the BSDF of an occluded sample (:933-935, :949-951): an occluded sample must contribute nothing even
+        // when its (pre-evaluated) pending term is NaN, hence the guard instead of a bare multiply by 0.
+        if (kind == KIND_SHADOW_ENV) { if (transmission > 0.0f) L += pend_env * transmission; }
+        else if (kind == KIND_SHADOW_LIGHT) { if (transmission > 0.0f) L += pend_light * transmission; }
         else if (!got) {
             // Miss :1037-1051
             vec3 c;
