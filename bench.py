@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--save-image", default="")
+    ap.add_argument("--mode", default="wavefront", choices=["wavefront", "megakernel"])
+    ap.add_argument("--stage-blocks", type=int, default=0)
     args = ap.parse_args()
 
     import numpy as np
@@ -77,6 +79,7 @@ def main():
         s.width, s.height = args.width, args.height
 
     r = Renderer(device=local_rank)
+    r.set_kernel_mode(abi.MODE_MEGAKERNEL if args.mode == "megakernel" else abi.MODE_WAVEFRONT, args.stage_blocks)
     h = s.upload(r)
     r.build_accel()
     settings = s.settings

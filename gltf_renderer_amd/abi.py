@@ -67,6 +67,7 @@ MESH_FLAG_INDEX, MESH_FLAG_TANGENT_SPACE, MESH_FLAG_TEXCOORD_0 = 1, 2, 4
 MESH_FLAG_TEXCOORD_1, MESH_FLAG_COLOR, MESH_FLAG_JOINT_WEIGHT = 8, 16, 32
 DYNAMIC_MESH_FLAG_POSITION, DYNAMIC_MESH_FLAG_TANGENT_SPACE = 1, 2
 TONEMAPPER_NONE, TONEMAPPER_AGX = 0, 1
+MODE_WAVEFRONT, MODE_MEGAKERNEL = 0, 1
 
 
 class PtSettings(C.Structure):

@@ -54,6 +54,9 @@ struct pt_ctx {
     float* d_srgb = nullptr;
     Counters* d_counters = nullptr;
     void* d_bones = nullptr; size_t bones_cap = 0;
+    void* d_workspace = nullptr; size_t workspace_cap = 0;     // wavefront ray / hit / path-state arrays
+    int kernel_mode = PT_MODE_WAVEFRONT;
+    int stage_blocks = 2048;
     hipEvent_t ev_trace[2] = {nullptr, nullptr}, ev_accel[2] = {nullptr, nullptr}, ev_skin[2] = {nullptr, nullptr};
     bool have_trace = false, have_accel = false, have_skin = false;
     int bounce_limit = PT_REFERENCE_MAX_BOUNCES;
@@ -232,7 +235,18 @@ public:
             fc.my_tiles = ntiles > fc.tile_rank ? (ntiles - fc.tile_rank + fc.tile_rank_count - 1) / fc.tile_rank_count : 0;
 
             HIPOK(hipEventRecord(ctx->ev_trace[0], ctx->stream));
-            launch_megakernel(sc, fc, (float4*)ep->output, ctx->d_counters, ctx->counters_enabled, ctx->stream);   // :344-353
+            if (ctx->kernel_mode == PT_MODE_MEGAKERNEL) {
+                launch_megakernel(sc, fc, (float4*)ep->output, ctx->d_counters, ctx->counters_enabled, ctx->stream);   // :344-353
+            } else {
+                size_t need = wavefront_workspace_bytes(fc.my_tiles * 256u, ctx->stage_blocks);
+                if (need > ctx->workspace_cap) {
+                    HIPOK(hipStreamSynchronize(ctx->stream));
+                    hipFree(ctx->d_workspace); ctx->d_workspace = nullptr; ctx->workspace_cap = 0;
+                    HIPOK(hipMalloc(&ctx->d_workspace, need));
+                    ctx->workspace_cap = need;
+                }
+                HIPOK(launch_wavefront(sc, fc, (float4*)ep->output, ctx->d_counters, ctx->counters_enabled, ctx->d_workspace, ctx->stage_blocks, ctx->stream));
+            }
             HIPOK(hipGetLastError());
             HIPOK(hipEventRecord(ctx->ev_trace[1], ctx->stream));
             ctx->have_trace = true;
@@ -361,6 +375,7 @@ void pt_destroy(pt_ctx* ctx) {
     hipFree(ctx->d_instances); hipFree(ctx->d_nodes); hipFree(ctx->d_tris); hipFree(ctx->d_sheen); hipFree(ctx->d_srgb); hipFree(ctx->d_counters);
     accel_scratch_free(ctx->scratch);
     hipFree(ctx->d_bones);
+    hipFree(ctx->d_workspace);
     for (int i = 0; i < 2; i++) {
         if (ctx->ev_trace[i]) hipEventDestroy(ctx->ev_trace[i]);
         if (ctx->ev_accel[i]) hipEventDestroy(ctx->ev_accel[i]);
@@ -542,6 +557,13 @@ int pt_trace(pt_ctx* ctx, const pt_settings* settings, const pt_execute_params* 
 int pt_set_bounce_limit(pt_ctx* ctx, int limit) {
     if (!ctx || limit < 0) return PT_ERR_INVALID_ARGUMENT;
     ctx->bounce_limit = limit;
+    return PT_OK;
+}
+
+int pt_set_kernel_mode(pt_ctx* ctx, int mode, int stage_blocks) {
+    if (!ctx || (mode != PT_MODE_WAVEFRONT && mode != PT_MODE_MEGAKERNEL)) return PT_ERR_INVALID_ARGUMENT;
+    ctx->kernel_mode = mode;
+    if (stage_blocks > 0) ctx->stage_blocks = stage_blocks;
     return PT_OK;
 }
 

@@ -57,5 +57,8 @@ void launch_tonemap(const float4* in, uint32_t w, uint32_t h, const pt_tonemap_c
 
 // ---- pt_kernel.hip ----------------------------------------------------------------------------
 void launch_megakernel(const SceneRec& sc, const FrameConstants& fc, float4* output, Counters* counters, bool count, hipStream_t stream);
+size_t wavefront_workspace_bytes(uint32_t slots, int stage_blocks);
+hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4* output, Counters* counters, bool count, void* workspace,
+                            int stage_blocks, hipStream_t stream);
 
 }  // namespace pt

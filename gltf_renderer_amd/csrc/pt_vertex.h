@@ -1,0 +1,245 @@
+// pt_vertex.h -- one path vertex of the iterative path tracer (shared by the megakernel and the wavefront
+// shade stage).
+//
+// shade_closest_hit() is ClosestHit (Source/Shaders/PathTracer.lib.hlsl:788-1007) with the recursion removed:
+// all random numbers of the vertex are drawn in the reference's order (env NEE, light NEE, BSDF, Russian
+// roulette) and the up-to-three follow-up rays are returned as a queue, each shadow ray with its pending
+// contribution already multiplied by the path weight beta.  shade_miss() is Miss (:1037-1051).
+#pragma once
+#include "pt_traverse.h"
+
+namespace pt {
+
+struct PathState {          // Payload (PathTracer.lib.hlsl:110-117) made iterative
+    vec3 beta, thr;         // product of bounce weights / the reference's payload.throughput (feeds RR only)
+    float prev_pdf;
+    int rc, bounce;
+    bool prev_mis;
+};
+
+struct Followups {
+    vec3 add;               // beta-weighted radiance to add to L right away (emissive, untraced NEE, debug colour)
+    bool overwrite;         // debug outputs of :969-990 overwrite payload.color
+    bool q_env, q_light, q_bounce;
+    vec3 pend_env, env_dir, pend_light, light_dir, origin_above;
+    vec3 b_o, b_d, b_beta, b_thr;
+    float b_pdf;
+    bool b_mis;
+    unsigned counted_shadow;   // shadow rays the reference traces but whose result a debug mode discards
+};
+
+PT_DEV vec3 shade_miss(const SceneRec& sc, const FrameConstants& fc, vec3 dir, const PathState& ps) {
+    const uint32_t flags = fc.flags;
+    vec3 c;
+    if (flags & PT_FLAG_ENVIRONMENT_MAP) {
+        c = sc.has_env ? fc.environment_intensity * sample_cube(sc.env.cube, sc.env.cube_n, dir) : v3(0);
+        if ((flags & PT_FLAG_ENVIRONMENT_MIS) && ps.prev_mis) {
+            float env_pdf = sc.has_env ? importance_map_pdf(sc.env, square_to_uv(sphere_to_square(normalize(dir)))) / (4 * kPi) : 0.f;
+            c *= ps.prev_pdf / (ps.prev_pdf + env_pdf);                                              // BalanceHeuristic :383-386
+        }
+    } else c = fc.environment_intensity * v3p(fc.environment_color);
+    return ps.beta * c;
+}
+
+// Returns true when the path ends at this vertex for a debug output (fu.add holds beta * debug colour).
+PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint32_t px, uint32_t py, const Ray& ray, const HitRec& hit,
+                              PathState& ps, Followups& fu, unsigned& taps) {
+    const uint32_t flags = fc.flags;
+    fu.add = v3(0); fu.overwrite = false; fu.counted_shadow = 0;
+    fu.q_env = fu.q_light = fu.q_bounce = false;
+    const float4* tp = (const float4*)sc.tris + (size_t)hit.tri * 3;
+    const uint32_t inst_id = __float_as_uint(tp[0].w), prim = __float_as_uint(tp[1].w);
+    const pt_mesh_instance& inst = sc.instances[inst_id].gpu;
+    const pt_material& mat = sc.materials[inst.material_id];
+    HitGeom va = get_vertex_attributes(sc, inst, prim, v3(1 - hit.u - hit.v, hit.u, hit.v));
+    const int dbg = fc.debug_output;
+    if (dbg >= PT_DEBUG_OUTPUT_HIT_KIND && dbg <= PT_DEBUG_OUTPUT_TEXCOORD_1) {                       // :806-840
+        vec3 c;
+        switch (dbg) {
+            case PT_DEBUG_OUTPUT_HIT_KIND: c = hit.front ? v3(1, 0, 0) : v3(0, 1, 0); break;
+            case PT_DEBUG_OUTPUT_VERTEX_COLOR: c = xyz(va.color); break;
+            case PT_DEBUG_OUTPUT_VERTEX_ALPHA: c = v3(va.color.w); break;
+            case PT_DEBUG_OUTPUT_VERTEX_NORMAL: c = (va.n + 1) / 2; break;
+            case PT_DEBUG_OUTPUT_VERTEX_TANGENT: c = (va.t + 1) / 2; break;
+            case PT_DEBUG_OUTPUT_VERTEX_BITANGENT: c = (va.bt + 1) / 2; break;
+            case PT_DEBUG_OUTPUT_TEXCOORD_0: c = v3(va.tc[0].x, va.tc[0].y, 0); break;
+            default: c = v3(va.tc[1].x, va.tc[1].y, 0); break;
+        }
+        fu.add = ps.beta * c;
+        return true;
+    }
+    if (!hit.front) { va.ng = -va.ng; va.n = -va.n; va.t = -va.t; va.tw = -va.tw; }                  // :842-846 (float4 negation: w too)
+    const vec3 intersection = ray.o + (ray.d * hit.t);                                               // :849
+    const vec3 o_above = offset_ray(va.position, va.ng), o_below = offset_ray(va.position, -va.ng);
+    const vec3 view = -normalize(ray.d);
+    Surface sp = get_surface(sc, flags, mat, va, view, taps);
+    if (dbg >= PT_DEBUG_OUTPUT_COLOR && dbg <= PT_DEBUG_OUTPUT_TRANSMISSIVE) {                       // :863-917
+        vec3 c;
+        switch (dbg) {
+            case PT_DEBUG_OUTPUT_COLOR: c = sp.albedo; break;
+            case PT_DEBUG_OUTPUT_ALPHA: c = v3(sp.alpha); break;
+            case PT_DEBUG_OUTPUT_SHADING_NORMAL: c = (sp.n + 1) / 2; break;
+            case PT_DEBUG_OUTPUT_SHADING_TANGENT: c = (sp.at + 1) / 2; break;
+            case PT_DEBUG_OUTPUT_SHADING_BITANGENT: c = (sp.ab + 1) / 2; break;
+            case PT_DEBUG_OUTPUT_METALNESS: c = v3(sp.metalness); break;
+            case PT_DEBUG_OUTPUT_ROUGHNESS: c = v3(sqrtf(sp.ay)); break;
+            case PT_DEBUG_OUTPUT_SPECULAR: c = v3(sp.spec_factor); break;
+            case PT_DEBUG_OUTPUT_SPECULAR_COLOR: c = sp.spec_color; break;
+            case PT_DEBUG_OUTPUT_CLEARCOAT: c = v3(sp.clearcoat); break;
+            case PT_DEBUG_OUTPUT_CLEARCOAT_ROUGHNESS: c = v3(sp.cc_rough); break;
+            case PT_DEBUG_OUTPUT_CLEARCOAT_NORMAL: c = (sp.cc_n + 1) / 2; break;
+            default: c = v3(sp.transmissive); break;
+        }
+        fu.add = ps.beta * c;
+        return true;
+    }
+    if (dbg == PT_DEBUG_OUTPUT_HEMISPHERE_VIEW_SIDE) {                                               // :919-922
+        fu.add = ps.beta * (dot(view, sp.n) > 0 ? v3(0, 1, 0) : v3(1, 0, 0));
+        return true;
+    }
+    const Lobes lobes = lobe_probabilities(sp, view);
+    vec3 c = emissive_of(sc, mat, va.tc, taps);                                                      // :925-926
+    fu.origin_above = o_above;
+    // environment NEE :929-942 (SampleEnvironmentMap :688-703)
+    if (ps.bounce < fc.max_bounces && (flags & PT_FLAG_ENVIRONMENT_MAP) && (flags & PT_FLAG_ENVIRONMENT_MIS)) {
+        vec4 r = next_random(px, py, fc.seed, ps.rc);
+        float light_pdf = 1;
+        vec3 ldir = v3(0, 0, 1), lcol = v3(0);
+        if (sc.has_env) {
+            vec2 uv = sample_importance_map(sc.env, r.x, r.y, light_pdf);
+            ldir = square_to_sphere(uv_to_square(uv));
+            light_pdf /= 4 * kPi;
+            lcol = fc.environment_intensity * sample_cube(sc.env.cube, sc.env.cube_n, ldir);
+        }
+        vec3 contrib = v3(0);
+        if (any_gt0(lcol)) {
+            float bp = 0;
+            vec3 f = evaluate_bsdf(flags, sc.sheen_e, sp, lobes, va.ng, view, ldir, bp);
+            float mis = light_pdf / (light_pdf + bp);
+            contrib = (mis * f * lcol) / light_pdf;
+        }
+        if (flags & PT_FLAG_INDIRECT_ENVIRONMENT_ONLY) c += contrib;                                 // TraceShadowRay returns 1 untraced (:726-728)
+        else { fu.q_env = true; fu.pend_env = ps.beta * contrib; fu.env_dir = ldir; }
+    }
+    // punctual-light NEE :945-956 (SamplePointLight :680-686)
+    if ((flags & PT_FLAG_POINT_LIGHTS) && fc.num_of_lights > 0) {
+        float u = next_random(px, py, fc.seed, ps.rc).x;
+        uint32_t li = f2u(u * (float)fc.num_of_lights);
+        li = min(li, (uint32_t)(fc.num_of_lights - 1));                                              // u may be exactly 1 (quirk q17)
+        float pdf = 1.0f / (float)fc.num_of_lights;
+        vec3 ldir, lcol;
+        light_ray(sc.lights[li], intersection, ldir, lcol);
+        vec3 contrib = v3(0);
+        if (any_gt0(lcol)) {
+            float bp = 0;
+            vec3 f = evaluate_bsdf(flags, sc.sheen_e, sp, lobes, va.ng, view, ldir, bp);
+            contrib = (lcol * f) / pdf;
+        }
+        if ((flags & PT_FLAG_SHADOW_RAYS) && !(flags & PT_FLAG_INDIRECT_ENVIRONMENT_ONLY)) { fu.q_light = true; fu.pend_light = ps.beta * contrib; fu.light_dir = ldir; }
+        else c += contrib;
+    }
+    fu.add = ps.beta * c;
+    // BSDF sampling + Russian roulette :958-1006
+    if (ps.bounce < fc.max_bounces) {
+        vec4 r = next_random(px, py, fc.seed, ps.rc);
+        bool is_tr = false, use_mis = false;
+        float bp = 1;
+        vec3 l = v3(0);
+        vec3 f = sample_bsdf(flags, sc.sheen_e, sp, lobes, v3(r.x, r.y, r.z), view, l, bp, is_tr, use_mis);
+        vec3 weight = bp != 0 ? f / bp : v3(0);
+        vec3 throughput = ps.thr * weight;
+        if (dbg >= PT_DEBUG_OUTPUT_BOUNCE_DIRECTION && dbg <= PT_DEBUG_BOUNCE_IS_TRANSMISSION) {     // :969-990
+            vec3 dc;
+            switch (dbg) {
+                case PT_DEBUG_OUTPUT_BOUNCE_DIRECTION: dc = 0.5f * (l + 1); break;
+                case PT_DEBUG_OUTPUT_BOUNCE_BSDF: dc = f; break;
+                case PT_DEBUG_OUTPUT_BOUNCE_PDF: dc = v3(bp); break;
+                case PT_DEBUG_OUTPUT_BOUNCE_WEIGHT: dc = weight; break;
+                default: dc = is_tr ? v3(0, 1, 0) : v3(1, 0, 0); break;
+            }
+            // payload.color is OVERWRITTEN here: emissive / NEE are discarded; the reference has already traced the NEE
+            // shadow rays by now, so they still count as rays.
+            fu.counted_shadow = (fu.q_env ? 1u : 0u) + (fu.q_light ? 1u : 0u);
+            fu.q_env = fu.q_light = false;
+            fu.add = ps.beta * dc;
+            fu.overwrite = true;
+            return true;
+        }
+        if (any_gt0(throughput)) {
+            float ur = next_random(px, py, fc.seed, ps.rc).x;                                        // drawn even below min_bounces (quirk q6)
+            bool cont = ps.bounce < fc.min_bounces;
+            if (!cont) {                                                                             // RussianRoulette :712-722
+                float p = clampf(max3(throughput), fc.min_rr, fc.max_rr);
+                if (ur < p) { weight = weight / p; cont = true; }
+            }
+            if (cont) {
+                fu.q_bounce = true;
+                fu.b_o = is_tr ? o_below : o_above;
+                fu.b_d = l;
+                fu.b_beta = ps.beta * weight;
+                fu.b_thr = throughput * weight;                                                      // weight applied twice (quirk q5)
+                fu.b_pdf = bp; fu.b_mis = use_mis;
+            }
+        }
+    }
+    return false;
+}
+
+// RayGeneration prologue :744-758 (GenerateCameraRay :131-142)
+PT_DEV Ray camera_ray(const FrameConstants& fc, uint32_t px, uint32_t py, int& rc) {
+    vec4 r = next_random(px, py, fc.seed, rc);
+    float jx = r.x - 0.5f, jy = r.y - 0.5f;
+    float cx = (((float)px + 0.5f + jx) / (float)fc.res_x) * 2 - 1;
+    float cy = (((float)py + 0.5f + jy) / (float)fc.res_y) * 2 - 1;
+    cy = -cy;
+    vec4 s = mul4(fc.clip_to_world, vec4{cx, cy, 1, 1});
+    vec4 e = mul4(fc.clip_to_world, vec4{cx, cy, 0, 1});
+    vec3 o = xyz(s) / s.w;
+    vec3 d = xyz(e) / e.w - o;
+    Ray ray;
+    ray.o = o; ray.tmin = 0; ray.d = normalize(d); ray.tmax = length(d);
+    return ray;
+}
+
+// RayGeneration epilogue :760-785
+PT_DEV void write_pixel(const FrameConstants& fc, float4* __restrict__ output, uint32_t px, uint32_t py, vec3 L) {
+    const uint32_t flags = fc.flags;
+    if (any_nan(L)) L = (flags & PT_FLAG_SHOW_NAN) ? v3(1, 0, 0) : v3(0);
+    if (any_inf(L)) L = (flags & PT_FLAG_SHOW_INF) ? v3(1, 0, 0) : v3(0);
+    if (flags & PT_FLAG_LUMINANCE_CLAMP) {
+        float lum = luminance(L);
+        if (lum > fc.luminance_clamp) L *= fc.luminance_clamp / lum;
+    }
+    float4* outp = output + ((size_t)py * fc.res_x + px);
+    if ((flags & PT_FLAG_ACCUMULATE) && fc.accumulated_frames != 0) {
+        float4 h = *outp;
+        float blend = 1.0f / ((float)fc.accumulated_frames + 1.0f);
+        *outp = make_float4(h.x + blend * (L.x - h.x), h.y + blend * (L.y - h.y), h.z + blend * (L.z - h.z), h.w + blend * (1.0f - h.w));
+    } else *outp = make_float4(L.x, L.y, L.z, 1.0f);
+}
+
+// tile-sharded pixel of a (rank-local) slot: slot -> (tile of this rank, lane in tile), one wave64 per 8x8 quadrant
+PT_DEV bool slot_pixel(const FrameConstants& fc, uint32_t slot, uint32_t& px, uint32_t& py) {
+    const uint32_t local_tile = slot >> 8, t = slot & 255;
+    const uint32_t tile = fc.tile_rank + local_tile * fc.tile_rank_count;
+    const uint32_t tx = tile % fc.tiles_x, ty = tile / fc.tiles_x;
+    const uint32_t wave = t >> 6, lane = t & 63;
+    px = tx * PT_TILE + (wave & 1) * 8 + (lane & 7);
+    py = ty * PT_TILE + (wave >> 1) * 8 + (lane >> 3);
+    return (px < fc.res_x) && (py < fc.res_y) && (tile < fc.tiles_x * fc.tiles_y);
+}
+
+// wave64 reduction of the per-lane tallies, one atomic per wave per counter
+PT_DEV void flush_counters(Counters* __restrict__ counters, uint32_t lane, unsigned n_primary, unsigned n_bounce, unsigned n_shadow, unsigned n_hits,
+                           const LaneStats& st) {
+    unsigned vals[8] = {n_primary, n_bounce, n_shadow, st.nodes, st.tris, n_hits, st.taps, st.overflow};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        unsigned v = vals[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0 && v) atomicAdd(((unsigned long long*)counters) + k, (unsigned long long)v);
+    }
+}
+
+}  // namespace pt

@@ -1,0 +1,327 @@
+// pt_wavefront.hip -- staged (wavefront) arrangement of the path tracer for gfx950.
+//
+// The frame advances one path vertex at a time through three stages -- trace (closest hit) -> shade ->
+// trace (shadow) -- over SoA ray / hit / path-state arrays in HBM (coalesced 16-B-per-lane float4 records).
+// The trace stages are small-register kernels that run at 6 waves/SIMD to hide the dependent-load latency
+// of BVH traversal; the heavy material code runs only on lanes that have a hit.  MI355X has HBM bandwidth
+// to spare (the state traffic is ~300 B per vertex against 8 TB/s) but no RT cores, so occupancy and full
+// waves are what buy ray throughput.
+//
+// Queues are SHARDED: kShards self-contained sub-pipelines.  Workgroup b of every stage launch belongs to
+// shard b % kShards; it consumes only its shard's queue segment and pushes only into its shard's segments,
+// so an entry never migrates and each segment's size is bounded by what the generate stage put there.
+// Surviving paths are compacted with a wave64 ballot and ONE atomic per wave on the shard's counter --
+// 32 waves per counter instead of 32 k on one word (a single word saturates at ~88 atomics/us on this
+// chip, which made an unsharded queue the bottleneck of every stage).
+//
+// Determinism: a pixel's radiance is accumulated in its own slot in a fixed order (hit terms, then the
+// env-shadow term, then the light-shadow term of that vertex), independent of queue order, so frames are
+// bit-reproducible and N tile shards compose bit-exactly.
+#include "pt_vertex.h"
+#include "pt_host.h"
+
+namespace pt {
+
+constexpr uint32_t kShards = 256;
+constexpr uint32_t kMissTri = 0x7fffffffu;
+constexpr uint32_t kCounterStride = 16;      // one 64-B line per shard counter
+
+struct WfBuffers {
+    // per slot (one path per pixel of this rank)
+    float4* L;            // xyz radiance so far
+    float4* beta_pdf;     // beta.xyz, prev_pdf
+    float4* thr_misc;     // thr.xyz, bits: rc | bounce << 16 | prev_mis << 31
+    float4* pend_env;     // xyz pending env-NEE term (beta-weighted), w = shadow transmission (written by the shadow stage)
+    float4* pend_light;   // same for the punctual-light term
+    uint32_t* pflags;     // bit 0 env pending, bit 1 light pending
+    // closest-ray queues (ping-pong), kShards segments of seg_cap entries: (o.xyz, tmax), (d.xyz, slot)
+    float4* ray_o[2];
+    float4* ray_d[2];
+    float4* hit;          // per entry of the current queue: t, u, v, bits: tri | front << 31 (kMissTri: miss)
+    // shadow queue, kShards segments of 2 * seg_cap entries: (o.xyz, bits: slot | is_light << 31), (d.xyz, tmax)
+    float4* sh_o;
+    float4* sh_d;
+    uint32_t* cnt[3];     // per-shard entry counts: closest queue 0, closest queue 1, shadow queue (stride kCounterStride)
+    uint32_t capacity;    // slots
+    uint32_t seg_cap;     // entries per closest-queue segment
+    uint32_t blocks_per_shard;
+};
+
+// wave64 ballot compaction into a shard counter: lanes with `pred` get consecutive indices; one atomic per wave.
+PT_DEV uint32_t queue_push(uint32_t* counter, bool pred) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0) return 0;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+    uint32_t base = 0;
+    const int leader = __ffsll((long long)m) - 1;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    return base + rank;
+}
+
+// Every stage launch has the same grid: kShards * blocks_per_shard workgroups.  Workgroup b: shard b % kShards, member b / kShards.
+struct ShardView { uint32_t shard, member, stride; };
+PT_DEV ShardView shard_view(const WfBuffers& wf) {
+    ShardView v;
+    v.shard = blockIdx.x % kShards;
+    v.member = blockIdx.x / kShards;
+    v.stride = wf.blocks_per_shard * kBlock;
+    return v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_wf_generate(FrameConstants fc, WfBuffers wf, Counters* __restrict__ counters) {
+    const ShardView sv = shard_view(wf);
+    const uint32_t total = gridDim.x * kBlock;
+    const uint32_t rounds = (wf.capacity + total - 1) / total;
+    unsigned n_primary = 0;
+    for (uint32_t rnd = 0; rnd < rounds; rnd++) {
+        // a workgroup-round is 256 consecutive slots = one 16x16 tile: primary rays stay coherent per wave (8x8 quadrant)
+        const uint32_t slot = (rnd * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+        uint32_t px = 0, py = 0;
+        const bool valid = slot < wf.capacity && slot_pixel(fc, slot, px, py);
+        int rc = 0;
+        Ray ray;
+        ray.o = v3(0); ray.d = v3(0, 0, 1); ray.tmin = 0; ray.tmax = 0;
+        if (valid) ray = camera_ray(fc, px, py, rc);
+        const uint32_t idx = queue_push(wf.cnt[0] + sv.shard * kCounterStride, valid);
+        if (valid) {
+            const size_t e = (size_t)sv.shard * wf.seg_cap + idx;
+            wf.ray_o[0][e] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.tmax);
+            wf.ray_d[0][e] = make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(slot));
+            wf.L[slot] = make_float4(0, 0, 0, 0);
+            wf.beta_pdf[slot] = make_float4(1, 1, 1, 0);
+            wf.thr_misc[slot] = make_float4(1, 1, 1, __uint_as_float((uint32_t)rc));
+            wf.pflags[slot] = 0;
+            n_primary++;
+        }
+    }
+    LaneStats st = {0, 0, 0, 0};
+    flush_counters(counters, threadIdx.x & 63, n_primary, 0, 0, 0, st);
+}
+
+// closest-hit traversal of queue `cur`; member 0 of each shard also zeroes the counters the following shade stage fills.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_wf_trace(SceneRec sc, WfBuffers wf, int cur, uint32_t rf, uint32_t rmask, Counters* __restrict__ counters) {
+    __shared__ int s_stack[kStackLds * kBlock];
+    int* my_stack = s_stack + threadIdx.x;
+    const ShardView sv = shard_view(wf);
+    if (sv.member == 0 && threadIdx.x == 0) { wf.cnt[cur ^ 1][sv.shard * kCounterStride] = 0; wf.cnt[2][sv.shard * kCounterStride] = 0; }
+    const uint32_t n = wf.cnt[cur][sv.shard * kCounterStride];
+    const size_t base = (size_t)sv.shard * wf.seg_cap;
+    LaneStats st = {0, 0, 0, 0};
+    for (uint32_t i = sv.member * kBlock + threadIdx.x; i < n; i += sv.stride) {
+        const float4 o = wf.ray_o[cur][base + i], d = wf.ray_d[cur][base + i];
+        Ray ray;
+        ray.o = v3(o.x, o.y, o.z); ray.tmin = 0; ray.d = v3(d.x, d.y, d.z); ray.tmax = o.w;
+        HitRec hit;
+        float tr = 0;
+        const bool got = traverse<COUNT>(sc, my_stack, ray, rf, rmask, 0, hit, tr, st);
+        const uint32_t bits = got ? ((uint32_t)hit.tri | (hit.front ? 0x80000000u : 0u)) : kMissTri;
+        wf.hit[base + i] = make_float4(hit.t, hit.u, hit.v, __uint_as_float(bits));
+    }
+    if (COUNT) flush_counters(counters, threadIdx.x & 63, 0, 0, 0, 0, st);
+    else if (st.overflow) atomicAdd(&counters->stack_overflow, (unsigned long long)st.overflow);
+}
+
+// The reference multiplies the light colour by the shadow transmission BEFORE `if (any(color > 0))` and never evaluates
+// the BSDF of an occluded sample: an occluded sample contributes nothing even when its pending term is NaN.
+PT_DEV void apply_pending(const WfBuffers& wf, uint32_t slot, vec3& L) {
+    const uint32_t pf = wf.pflags[slot];
+    if (pf & 1u) { float4 p = wf.pend_env[slot]; if (p.w > 0.0f) L += v3(p.x, p.y, p.z) * p.w; }
+    if (pf & 2u) { float4 p = wf.pend_light[slot]; if (p.w > 0.0f) L += v3(p.x, p.y, p.z) * p.w; }
+}
+
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 2      // waves per SIMD the register allocator must leave room for (2 -> <= 256 VGPR+AGPR)
+#endif
+__global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc, FrameConstants fc, WfBuffers wf, int cur, Counters* __restrict__ counters) {
+    const ShardView sv = shard_view(wf);
+    const uint32_t n = wf.cnt[cur][sv.shard * kCounterStride];
+    const int nxt = cur ^ 1;
+    const size_t base = (size_t)sv.shard * wf.seg_cap, sbase = (size_t)sv.shard * wf.seg_cap * 2;
+    uint32_t* cnt_next = wf.cnt[nxt] + sv.shard * kCounterStride;
+    uint32_t* cnt_shadow = wf.cnt[2] + sv.shard * kCounterStride;
+    unsigned n_bounce = 0, n_shadow = 0, n_hits = 0;
+    LaneStats st = {0, 0, 0, 0};
+    const uint32_t rounds = (n + sv.stride - 1) / sv.stride;      // uniform per workgroup: ballots inside stay wave-uniform
+    for (uint32_t rnd = 0; rnd < rounds; rnd++) {
+        const uint32_t i = rnd * sv.stride + sv.member * kBlock + threadIdx.x;
+        const bool active = i < n;
+        bool push_env = false, push_light = false, push_bounce = false;
+        Followups fu;
+        fu.q_env = fu.q_light = fu.q_bounce = false;
+        uint32_t slot = 0;
+        PathState ps;
+        ps.beta = v3(0); ps.thr = v3(0); ps.prev_pdf = 0; ps.rc = 0; ps.bounce = 0; ps.prev_mis = false;
+        if (active) {
+            const float4 o = wf.ray_o[cur][base + i], d = wf.ray_d[cur][base + i], h = wf.hit[base + i];
+            slot = __float_as_uint(d.w);
+            Ray ray;
+            ray.o = v3(o.x, o.y, o.z); ray.tmin = 0; ray.d = v3(d.x, d.y, d.z); ray.tmax = o.w;
+            const float4 bp = wf.beta_pdf[slot], tm = wf.thr_misc[slot];
+            const uint32_t misc = __float_as_uint(tm.w);
+            ps.beta = v3(bp.x, bp.y, bp.z); ps.prev_pdf = bp.w; ps.thr = v3(tm.x, tm.y, tm.z);
+            ps.rc = (int)(misc & 0xffffu); ps.bounce = (int)((misc >> 16) & 0x7fffu); ps.prev_mis = (misc >> 31) != 0;
+            float4 Lq = wf.L[slot];
+            vec3 L = v3(Lq.x, Lq.y, Lq.z);
+            apply_pending(wf, slot, L);
+            uint32_t pf = 0;
+            const uint32_t hb = __float_as_uint(h.w);
+            if (hb == kMissTri) L += shade_miss(sc, fc, ray.d, ps);
+            else {
+                HitRec hit;
+                hit.t = h.x; hit.u = h.y; hit.v = h.z; hit.tri = (int)(hb & 0x7fffffffu); hit.front = (hb >> 31) != 0;
+                uint32_t px, py;
+                slot_pixel(fc, slot, px, py);
+                n_hits++;
+                const bool done = shade_closest_hit(sc, fc, px, py, ray, hit, ps, fu, st.taps);
+                if (fu.overwrite) L = v3(0);
+                L += fu.add;
+                n_shadow += fu.counted_shadow;
+                if (!done) {
+                    push_env = fu.q_env; push_light = fu.q_light; push_bounce = fu.q_bounce;
+                    if (push_env) { pf |= 1u; wf.pend_env[slot] = make_float4(fu.pend_env.x, fu.pend_env.y, fu.pend_env.z, 0.0f); }
+                    if (push_light) { pf |= 2u; wf.pend_light[slot] = make_float4(fu.pend_light.x, fu.pend_light.y, fu.pend_light.z, 0.0f); }
+                }
+            }
+            wf.L[slot] = make_float4(L.x, L.y, L.z, 0);
+            wf.pflags[slot] = pf;
+        }
+        // ---- compaction into this shard's shadow segment and next closest-ray segment (wave-uniform control flow)
+        const uint32_t ie = queue_push(cnt_shadow, push_env);
+        if (push_env) {
+            wf.sh_o[sbase + ie] = make_float4(fu.origin_above.x, fu.origin_above.y, fu.origin_above.z, __uint_as_float(slot));
+            wf.sh_d[sbase + ie] = make_float4(fu.env_dir.x, fu.env_dir.y, fu.env_dir.z, fc.max_ray_length);
+            n_shadow++;
+        }
+        const uint32_t il = queue_push(cnt_shadow, push_light);
+        if (push_light) {
+            wf.sh_o[sbase + il] = make_float4(fu.origin_above.x, fu.origin_above.y, fu.origin_above.z, __uint_as_float(slot | 0x80000000u));
+            wf.sh_d[sbase + il] = make_float4(fu.light_dir.x, fu.light_dir.y, fu.light_dir.z, fc.max_ray_length);
+            n_shadow++;
+        }
+        const uint32_t ib = queue_push(cnt_next, push_bounce);
+        if (push_bounce) {                                                                           // TraceBounceRay :669-678
+            wf.ray_o[nxt][base + ib] = make_float4(fu.b_o.x, fu.b_o.y, fu.b_o.z, fc.max_ray_length);
+            wf.ray_d[nxt][base + ib] = make_float4(fu.b_d.x, fu.b_d.y, fu.b_d.z, __uint_as_float(slot));
+            wf.beta_pdf[slot] = make_float4(fu.b_beta.x, fu.b_beta.y, fu.b_beta.z, fu.b_pdf);
+            const uint32_t misc = ((uint32_t)ps.rc & 0xffffu) | ((uint32_t)(ps.bounce + 1) << 16) | (fu.b_mis ? 0x80000000u : 0u);
+            wf.thr_misc[slot] = make_float4(fu.b_thr.x, fu.b_thr.y, fu.b_thr.z, __uint_as_float(misc));
+            n_bounce++;
+        }
+    }
+    flush_counters(counters, threadIdx.x & 63, 0, n_bounce, n_shadow, n_hits, st);
+}
+
+// occlusion traversal of the shadow queue (TraceShadowRay :724-742); writes the transmission next to its pending term.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_wf_shadow(SceneRec sc, WfBuffers wf, uint32_t flags, Counters* __restrict__ counters) {
+    __shared__ int s_stack[kStackLds * kBlock];
+    int* my_stack = s_stack + threadIdx.x;
+    const ShardView sv = shard_view(wf);
+    const uint32_t n = wf.cnt[2][sv.shard * kCounterStride];
+    const size_t sbase = (size_t)sv.shard * wf.seg_cap * 2;
+    LaneStats st = {0, 0, 0, 0};
+    for (uint32_t i = sv.member * kBlock + threadIdx.x; i < n; i += sv.stride) {
+        const float4 o = wf.sh_o[sbase + i], d = wf.sh_d[sbase + i];
+        const uint32_t sb = __float_as_uint(o.w);
+        const uint32_t slot = sb & 0x7fffffffu;
+        const bool is_light = (sb >> 31) != 0;
+        Ray ray;
+        ray.o = v3(o.x, o.y, o.z); ray.tmin = 0; ray.d = v3(d.x, d.y, d.z); ray.tmax = d.w;
+        const bool alpha_shadow = is_light && (flags & PT_FLAG_ALPHA_SHADOWS);
+        uint32_t srf = (flags & PT_FLAG_CULL_BACKFACE) ? RF_CULL_BACK : 0;
+        float transmission = 0.0f;
+        if (alpha_shadow) { transmission = 1.0f; srf |= RF_FORCE_NON_OPAQUE; }
+        else srf |= RF_ACCEPT_FIRST;
+        HitRec hit;
+        const bool got = traverse<COUNT>(sc, my_stack, ray, srf, 0xff, 1, hit, transmission, st);
+        if (!got) transmission = 1.0f;                                                               // ShadowMiss :1081-1085
+        float* w = is_light ? &wf.pend_light[slot].w : &wf.pend_env[slot].w;
+        *w = transmission;
+    }
+    if (COUNT) flush_counters(counters, threadIdx.x & 63, 0, 0, 0, 0, st);
+    else if (st.overflow) atomicAdd(&counters->stack_overflow, (unsigned long long)st.overflow);
+}
+
+__global__ __launch_bounds__(kBlock) void k_wf_resolve(FrameConstants fc, WfBuffers wf, float4* __restrict__ output) {
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t px, py;
+    if (slot >= wf.capacity || !slot_pixel(fc, slot, px, py)) return;
+    float4 Lq = wf.L[slot];
+    vec3 L = v3(Lq.x, Lq.y, Lq.z);
+    apply_pending(wf, slot, L);
+    write_pixel(fc, output, px, py, L);
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------
+static uint32_t blocks_per_shard_for(int stage_blocks) {
+    uint32_t b = (uint32_t)(stage_blocks > 0 ? stage_blocks : 2048) / kShards;
+    return b < 1 ? 1 : b;
+}
+static uint32_t seg_cap_for(uint32_t slots, uint32_t blocks_per_shard) {
+    // generate round r gives shard s the slots of workgroups {s, s + kShards, ...}: blocks_per_shard * 256 per round
+    const uint32_t total = kShards * blocks_per_shard * kBlock;
+    const uint32_t rounds = (slots + total - 1) / total;
+    return rounds * blocks_per_shard * kBlock;
+}
+
+size_t wavefront_workspace_bytes(uint32_t slots, int stage_blocks) {
+    const uint32_t bps = blocks_per_shard_for(stage_blocks);
+    const size_t q = (size_t)kShards * seg_cap_for(slots, bps);
+    return (size_t)slots * (5 * 16 + 4) + q * (4 * 16 + 16 + 2 * 2 * 16) + 3 * kShards * kCounterStride * 4 + 32 * 256;
+}
+
+static WfBuffers carve(void* base, uint32_t slots, int stage_blocks) {
+    WfBuffers wf;
+    char* p = (char*)base;
+    auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+    wf.blocks_per_shard = blocks_per_shard_for(stage_blocks);
+    wf.seg_cap = seg_cap_for(slots, wf.blocks_per_shard);
+    const size_t q = (size_t)kShards * wf.seg_cap;
+    for (int k = 0; k < 3; k++) wf.cnt[k] = (uint32_t*)take((size_t)kShards * kCounterStride * 4);
+    wf.L = (float4*)take((size_t)slots * 16);
+    wf.beta_pdf = (float4*)take((size_t)slots * 16);
+    wf.thr_misc = (float4*)take((size_t)slots * 16);
+    wf.pend_env = (float4*)take((size_t)slots * 16);
+    wf.pend_light = (float4*)take((size_t)slots * 16);
+    wf.pflags = (uint32_t*)take((size_t)slots * 4);
+    for (int k = 0; k < 2; k++) { wf.ray_o[k] = (float4*)take(q * 16); wf.ray_d[k] = (float4*)take(q * 16); }
+    wf.hit = (float4*)take(q * 16);
+    wf.sh_o = (float4*)take(q * 2 * 16);
+    wf.sh_d = (float4*)take(q * 2 * 16);
+    wf.capacity = slots;
+    return wf;
+}
+
+hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4* output, Counters* counters, bool count, void* workspace,
+                            int stage_blocks, hipStream_t stream) {
+    if (fc.my_tiles == 0) return hipSuccess;
+    const uint32_t slots = fc.my_tiles * kBlock;
+    WfBuffers wf = carve(workspace, slots, stage_blocks);
+    hipError_t e = hipMemsetAsync(wf.cnt[0], 0, (size_t)3 * kShards * kCounterStride * 4, stream);     // the three counter arrays are contiguous
+    if (e) return e;
+    const dim3 block(kBlock), full(fc.my_tiles), stage(kShards * wf.blocks_per_shard);
+    hipLaunchKernelGGL(k_wf_generate, stage, block, 0, stream, fc, wf, counters);
+    const uint32_t flags = fc.flags;
+    const int iterations = fc.debug_output != PT_DEBUG_OUTPUT_NONE ? 1 : fc.max_bounces + 1;
+    for (int b = 0; b < iterations; b++) {
+        const int cur = b & 1;
+        uint32_t rf, rmask = 0xff;
+        if (b == 0) rf = (flags & PT_FLAG_CULL_BACKFACE) ? RF_CULL_BACK : 0;                          // RayGeneration :747
+        else {                                                                                        // TraceBounceRay :671-672
+            rf = (flags & PT_FLAG_CULL_BACKFACE) ? RF_CULL_FRONT : 0;
+            rmask = (flags & PT_FLAG_INDIRECT_ENVIRONMENT_ONLY) ? 0 : 0xff;
+        }
+        if (count) hipLaunchKernelGGL(k_wf_trace<true>, stage, block, 0, stream, sc, wf, cur, rf, rmask, counters);
+        else hipLaunchKernelGGL(k_wf_trace<false>, stage, block, 0, stream, sc, wf, cur, rf, rmask, counters);
+        hipLaunchKernelGGL(k_wf_shade, stage, block, 0, stream, sc, fc, wf, cur, counters);
+        if (count) hipLaunchKernelGGL(k_wf_shadow<true>, stage, block, 0, stream, sc, wf, flags, counters);
+        else hipLaunchKernelGGL(k_wf_shadow<false>, stage, block, 0, stream, sc, wf, flags, counters);
+    }
+    hipLaunchKernelGGL(k_wf_resolve, full, block, 0, stream, fc, wf, output);
+    return hipGetLastError();
+}
+
+}  // namespace pt

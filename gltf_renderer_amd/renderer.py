@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmipt.so")
 # every symbol include/mipt.h declares
 EXPORTS = ["pt_abi_version", "pt_create", "pt_destroy", "pt_last_error", "pt_buffer_create", "pt_buffer_update", "pt_buffer_read",
            "pt_texture_create", "pt_sampler_create", "pt_scene_set_materials", "pt_scene_set_lights", "pt_scene_set_instances",
-           "pt_env_create", "pt_env_read", "pt_build_accel", "pt_skin_run", "pt_trace", "pt_set_bounce_limit", "pt_enable_counters",
+           "pt_env_create", "pt_env_read", "pt_build_accel", "pt_skin_run", "pt_trace", "pt_set_bounce_limit", "pt_enable_counters", "pt_set_kernel_mode",
            "pt_get_stats", "pt_reset_stats", "pt_readback", "pt_tonemap"]
 
 
@@ -62,6 +62,7 @@ def load_library():
     L.pt_trace.argtypes = [vp, vp, vp]
     L.pt_set_bounce_limit.argtypes = [vp, ci]
     L.pt_enable_counters.argtypes = [vp, ci]
+    L.pt_set_kernel_mode.argtypes = [vp, ci, ci]
     L.pt_get_stats.argtypes = [vp, vp]
     L.pt_reset_stats.argtypes = [vp]
     L.pt_readback.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp]
@@ -181,6 +182,10 @@ class Renderer:
 
     def enable_counters(self, on):
         self._check(self.L.pt_enable_counters(self.h, int(on)))
+
+    def set_kernel_mode(self, mode, stage_blocks=0):
+        """mode: abi.MODE_WAVEFRONT (default) or abi.MODE_MEGAKERNEL."""
+        self._check(self.L.pt_set_kernel_mode(self.h, mode, stage_blocks))
 
     def build_accel(self):
         self._check(self.L.pt_build_accel(self.h))

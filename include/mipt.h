@@ -363,6 +363,11 @@ int pt_skin_run(pt_ctx* ctx, const pt_skin_params* params, const pt_bone* bones,
 int pt_trace(pt_ctx* ctx, const pt_settings* settings, const pt_execute_params* params);
 int pt_set_bounce_limit(pt_ctx* ctx, int limit);      /* default PT_REFERENCE_MAX_BOUNCES */
 int pt_enable_counters(pt_ctx* ctx, int enable);      /* node / triangle / tap counters (slower) */
+/* Kernel arrangement (same per-vertex code, same results up to fp32 accumulation order): PT_MODE_WAVEFRONT (default) =
+ * staged trace / shade / shadow kernels over SoA ray queues in HBM with ballot compaction; PT_MODE_MEGAKERNEL = one
+ * lane per pixel-sample for the whole path.  stage_blocks: workgroups per wavefront stage launch (<= 0 keeps the default). */
+enum { PT_MODE_WAVEFRONT = 0, PT_MODE_MEGAKERNEL = 1 };
+int pt_set_kernel_mode(pt_ctx* ctx, int mode, int stage_blocks);
 /* Counters accumulate over pt_trace calls since the last pt_reset_stats; the *_ms fields are the
  * hipEvent times of the most recent call of each kind. */
 int pt_get_stats(pt_ctx* ctx, pt_stats* out);
