@@ -166,7 +166,7 @@ def main():
         env_mis = bool(settings.flags & abi.FLAG_ENVIRONMENT_MIS) and bool(settings.flags & abi.FLAG_ENVIRONMENT_MAP)
         # bytes/ray = N_node*64 + N_tri*48 + [closest hits] S_hit + 32/R per pixel-sample
         s_hit = 12 + 3 * (12 + 4 + 8) + 176 + 640            # indices + 3 vertices + instance row + material
-        alg = (c.nodes_visited * 64 + c.tris_tested * 48 + c.closest_hits * s_hit + c.texture_taps * 16
+        alg = (c.nodes_visited * 128 + c.tris_tested * 48 + c.closest_hits * s_hit + c.texture_taps * 16
                + (c.closest_hits * 40 * 4 if env_mis else 0) + (c.rays_primary + c.rays_bounce - c.closest_hits) * 64) / n + s.width * s.height * 32
         mean_ms = sum(kernel_ms) / len(kernel_ms)
         achieved = alg / (mean_ms * 1e-3) / 1e9

@@ -188,11 +188,61 @@ __global__ __launch_bounds__(256) void k_fit(const TriPacket* __restrict__ tris,
     }
 }
 
-static hipError_t ensure(AccelScratch& s, size_t n) {
-    if (n <= s.capacity) return hipSuccess;
+// 6. collapse to 4-wide.  Binary nodes at even depth are kept; each gathers its (up to 4) grandchildren, whose boxes are
+//    already stored in the intermediate (odd-depth) nodes.
+__global__ __launch_bounds__(256) void k_mark_kept(const int32_t* __restrict__ node_parent, uint32_t n_nodes, uint32_t* __restrict__ kept) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    uint32_t depth = 0;
+    int code = node_parent[i];
+    while (code >= 0) { depth++; code = node_parent[code >> 1]; }
+    kept[i] = (depth & 1u) ? 0u : 1u;
+}
+
+__device__ __forceinline__ void wide_set(Bvh4Node& w, int k, const float* lo, const float* hi, int32_t ref) {
+    w.lox[k] = lo[0]; w.loy[k] = lo[1]; w.loz[k] = lo[2]; w.hix[k] = hi[0]; w.hiy[k] = hi[1]; w.hiz[k] = hi[2]; w.child[k] = ref;
+}
+
+__global__ __launch_bounds__(256) void k_collapse(const BvhNode* __restrict__ nodes2, uint32_t n_nodes, const uint32_t* __restrict__ kept,
+                                                  const uint32_t* __restrict__ widx, Bvh4Node* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes || !kept[i]) return;
+    const BvhNode& n = nodes2[i];
+    Bvh4Node w;
+    int k = 0;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int32_t ch = c ? n.child1 : n.child0;
+        const float* lo = c ? n.lo1 : n.lo0;
+        const float* hi = c ? n.hi1 : n.hi0;
+        if (ch < 0) wide_set(w, k++, lo, hi, ch);                      // leaf child stays a leaf
+        else {                                                         // odd-depth inner node: adopt its two children
+            const BvhNode& m = nodes2[ch];
+            wide_set(w, k++, m.lo0, m.hi0, m.child0 < 0 ? m.child0 : (int32_t)widx[m.child0]);
+            wide_set(w, k++, m.lo1, m.hi1, m.child1 < 0 ? m.child1 : (int32_t)widx[m.child1]);
+        }
+    }
+    const float pinf[3] = {INFINITY, INFINITY, INFINITY}, ninf[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (; k < 4; k++) wide_set(w, k, pinf, ninf, kEmptyChild);
+    w._pad[0] = w._pad[1] = w._pad[2] = w._pad[3] = 0;
+    const float4* src = (const float4*)&w;
+    float4* dst = (float4*)(out + widx[i]);
+#pragma unroll
+    for (int q = 0; q < 8; q++) dst[q] = src[q];
+}
+
+static void free_all(AccelScratch& s) {
     hipFree(s.tris_unsorted); hipFree(s.keys_a); hipFree(s.keys_b); hipFree(s.vals_a); hipFree(s.vals_b);
     hipFree(s.leaf_parent); hipFree(s.node_parent); hipFree(s.flags); hipFree(s.sort_temp);
-    s.capacity = 0; s.sort_temp = nullptr; s.sort_temp_bytes = 0;
+    hipFree(s.nodes2); hipFree(s.kept); hipFree(s.widx); hipFree(s.scan_temp);
+}
+
+static hipError_t ensure(AccelScratch& s, size_t n) {
+    if (n <= s.capacity) return hipSuccess;
+    free_all(s);
+    uint32_t* bounds = s.bounds;
+    s = AccelScratch();
+    s.bounds = bounds;
     size_t cap = n + n / 8 + 64;
     hipError_t e;
     if ((e = hipMalloc(&s.tris_unsorted, cap * sizeof(TriPacket)))) return e;
@@ -203,25 +253,32 @@ static hipError_t ensure(AccelScratch& s, size_t n) {
     if ((e = hipMalloc(&s.leaf_parent, cap * 4))) return e;
     if ((e = hipMalloc(&s.node_parent, cap * 4))) return e;
     if ((e = hipMalloc(&s.flags, cap * 4))) return e;
+    if ((e = hipMalloc(&s.nodes2, cap * sizeof(BvhNode)))) return e;
+    if ((e = hipMalloc(&s.kept, (cap + 1) * 4))) return e;
+    if ((e = hipMalloc(&s.widx, (cap + 1) * 4))) return e;
     if (!s.bounds && (e = hipMalloc(&s.bounds, 6 * 4))) return e;
     size_t tb = 0;
     if ((e = rocprim::radix_sort_pairs(nullptr, tb, s.keys_a, s.keys_b, s.vals_a, s.vals_b, cap, 0, 63, (hipStream_t)0))) return e;
     if ((e = hipMalloc(&s.sort_temp, tb))) return e;
     s.sort_temp_bytes = tb;
+    size_t sb = 0;
+    if ((e = rocprim::exclusive_scan(nullptr, sb, s.kept, s.widx, 0u, cap + 1, rocprim::plus<uint32_t>(), (hipStream_t)0))) return e;
+    if ((e = hipMalloc(&s.scan_temp, sb))) return e;
+    s.scan_temp_bytes = sb;
     s.capacity = cap;
     return hipSuccess;
 }
 
 void accel_scratch_free(AccelScratch& s) {
-    hipFree(s.tris_unsorted); hipFree(s.keys_a); hipFree(s.keys_b); hipFree(s.vals_a); hipFree(s.vals_b);
-    hipFree(s.leaf_parent); hipFree(s.node_parent); hipFree(s.flags); hipFree(s.sort_temp); hipFree(s.bounds);
+    free_all(s);
+    hipFree(s.bounds);
     s = AccelScratch();
 }
 
-// Builds nodes (n_tris-1) and sorted packets (n_tris) into caller-provided arrays.  root_out: node 0, or ~0 for one triangle.
-hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const InstanceRec* d_instances, int n_inst, uint32_t n_tris, BvhNode* d_nodes,
-                       TriPacket* d_tris, int32_t* root_out, hipStream_t stream) {
+hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const InstanceRec* d_instances, int n_inst, uint32_t n_tris, Bvh4Node* d_nodes,
+                       TriPacket* d_tris, int32_t* root_out, uint32_t* wide_nodes_out, hipStream_t stream) {
     *root_out = 0;
+    *wide_nodes_out = 0;
     if (n_tris == 0) return hipSuccess;
     hipError_t e = ensure(s, n_tris);
     if (e) return e;
@@ -237,9 +294,17 @@ hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const Instan
     if ((e = rocprim::radix_sort_pairs(s.sort_temp, tb, s.keys_a, s.keys_b, s.vals_a, s.vals_b, (size_t)n_tris, 0, 63, stream))) return e;
     hipLaunchKernelGGL(k_reorder, dim3(g), dim3(256), 0, stream, s.tris_unsorted, s.vals_b, n_tris, d_tris);
     if ((e = hipMemsetAsync(s.flags, 0, (size_t)n_tris * 4, stream))) return e;
-    hipLaunchKernelGGL(k_hierarchy, dim3(g), dim3(256), 0, stream, s.keys_b, (int)n_tris, d_nodes, s.node_parent, s.leaf_parent);
-    hipLaunchKernelGGL(k_fit, dim3(g), dim3(256), 0, stream, d_tris, n_tris, d_nodes, s.node_parent, s.leaf_parent, s.flags);
-    return hipGetLastError();
+    hipLaunchKernelGGL(k_hierarchy, dim3(g), dim3(256), 0, stream, s.keys_b, (int)n_tris, s.nodes2, s.node_parent, s.leaf_parent);
+    hipLaunchKernelGGL(k_fit, dim3(g), dim3(256), 0, stream, d_tris, n_tris, s.nodes2, s.node_parent, s.leaf_parent, s.flags);
+    const uint32_t n_nodes = n_tris - 1;
+    hipLaunchKernelGGL(k_mark_kept, dim3(g), dim3(256), 0, stream, s.node_parent, n_nodes, s.kept);
+    if ((e = hipMemsetAsync(s.kept + n_nodes, 0, 4, stream))) return e;            // sentinel: widx[n_nodes] = total kept
+    size_t sb = s.scan_temp_bytes;
+    if ((e = rocprim::exclusive_scan(s.scan_temp, sb, s.kept, s.widx, 0u, (size_t)n_nodes + 1, rocprim::plus<uint32_t>(), stream))) return e;
+    hipLaunchKernelGGL(k_collapse, dim3(g), dim3(256), 0, stream, s.nodes2, n_nodes, s.kept, s.widx, d_nodes);
+    if ((e = hipGetLastError())) return e;
+    if ((e = hipMemcpyAsync(wide_nodes_out, s.widx + n_nodes, 4, hipMemcpyDeviceToHost, stream))) return e;
+    return hipStreamSynchronize(stream);
 }
 
 }  // namespace pt

@@ -44,7 +44,8 @@ struct pt_ctx {
     std::vector<InstanceRec> instances;
     InstanceRec* d_instances = nullptr; size_t instances_cap = 0;
     uint32_t n_tris = 0;
-    BvhNode* d_nodes = nullptr; TriPacket* d_tris = nullptr; size_t accel_cap = 0;
+    Bvh4Node* d_nodes = nullptr; TriPacket* d_tris = nullptr; size_t accel_cap = 0;
+    uint32_t wide_nodes = 0;
     int32_t root = 0;
     AccelScratch scratch;
     bool accel_dirty = true;
@@ -162,13 +163,13 @@ public:
             hipFree(ctx->d_nodes); hipFree(ctx->d_tris);
             ctx->d_nodes = nullptr; ctx->d_tris = nullptr;
             size_t cap = need + need / 8 + 64;
-            HIPOK(hipMalloc((void**)&ctx->d_nodes, cap * sizeof(BvhNode)));
+            HIPOK(hipMalloc((void**)&ctx->d_nodes, cap * sizeof(Bvh4Node)));
             HIPOK(hipMalloc((void**)&ctx->d_tris, cap * sizeof(TriPacket)));
             ctx->accel_cap = cap;
         }
         HIPOK(hipEventRecord(ctx->ev_accel[0], ctx->stream));
         HIPOK(accel_build(ctx->scratch, ctx->d_buffers, ctx->d_instances, (int)ctx->instances.size(), ctx->n_tris, ctx->d_nodes, ctx->d_tris,
-                          &ctx->root, ctx->stream));
+                          &ctx->root, &ctx->wide_nodes, ctx->stream));
         HIPOK(hipEventRecord(ctx->ev_accel[1], ctx->stream));
         ctx->have_accel = true;
         ctx->accel_dirty = false;
@@ -592,7 +593,7 @@ int pt_get_stats(pt_ctx* ctx, pt_stats* out) {
     if (ctx->have_accel) hipEventElapsedTime(&out->accel_ms, ctx->ev_accel[0], ctx->ev_accel[1]);
     if (ctx->have_skin) hipEventElapsedTime(&out->skin_ms, ctx->ev_skin[0], ctx->ev_skin[1]);
     out->accumulated_frames = ctx->accumulated_frames;
-    out->bvh_nodes = ctx->n_tris > 1 ? ctx->n_tris - 1 : 0;
+    out->bvh_nodes = ctx->wide_nodes;
     out->bvh_triangles = ctx->n_tris;
     if (c.stack_overflow) return ctx->fail(PT_ERR_CAPACITY, "traversal stack overflow: " + std::to_string(c.stack_overflow) + " pushes dropped");
     return PT_OK;

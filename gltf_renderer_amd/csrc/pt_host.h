@@ -17,11 +17,17 @@ struct AccelScratch {
     uint32_t* bounds = nullptr;      // 6 sortable-uint floats: min xyz, max xyz
     void* sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
+    BvhNode* nodes2 = nullptr;       // the binary LBVH (intermediate)
+    uint32_t* kept = nullptr;        // 1 for binary nodes at even depth: they become 4-wide nodes
+    uint32_t* widx = nullptr;        // exclusive scan of kept = wide node index
+    void* scan_temp = nullptr;
+    size_t scan_temp_bytes = 0;
     size_t capacity = 0;
 };
 void accel_scratch_free(AccelScratch& s);
-hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const InstanceRec* d_instances, int n_inst, uint32_t n_tris, BvhNode* d_nodes,
-                       TriPacket* d_tris, int32_t* root_out, hipStream_t stream);
+// Builds the 4-wide BVH (<= n_tris nodes) and the sorted packets (n_tris).  root_out: 0, or ~0 for a single triangle.
+hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const InstanceRec* d_instances, int n_inst, uint32_t n_tris, Bvh4Node* d_nodes,
+                       TriPacket* d_tris, int32_t* root_out, uint32_t* wide_nodes_out, hipStream_t stream);
 
 // ---- envmap.hip -------------------------------------------------------------------------------
 struct EnvDevice {

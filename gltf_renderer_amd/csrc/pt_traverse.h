@@ -1,11 +1,15 @@
 // pt_traverse.h -- software BVH traversal for gfx950 (replaces DXR TraceRay).
 //
-// One lane = one ray.  While-while traversal of the 64-B BVH2 nodes (4 x dwordx4 loads per node, both
-// child boxes tested from registers), 48-B world-space triangle packets (3 x dwordx4), a per-lane stack
-// held in LDS ([depth][lane] layout: conflict-free ds_read/ds_write_b32) with a scratch spill for the
-// rare deep path.  DXR semantics kept: hit interval tmin < t < tmax, object-space facing (mirrored
-// instances flip), instance cull-disable / force-non-opaque flags, any-hit for MASK instances,
-// accept-first-hit occlusion rays, and the alpha-shadow transmittance product.
+// One lane = one ray.  While-while traversal of 128-B 4-wide nodes (7 x dwordx4 loads per node; each float4
+// holds one bound of all four children, so a slab test of the four boxes is straight VALU on registers),
+// children visited near-to-far (4-key sorting network on (entry distance | slot) packed in one uint),
+// 48-B world-space triangle packets (3 x dwordx4), a per-lane stack held in LDS ([depth][lane] layout:
+// conflict-free ds_read/ds_write_b32) with a scratch spill for the rare deep path.  Traversal is a chain of
+// dependent fetches that mostly hit L2 / Infinity Cache, i.e. latency-bound: the 4-wide node halves the
+// number of dependent steps of the binary LBVH it is collapsed from.
+// DXR semantics kept: hit interval tmin < t < tmax, object-space facing (mirrored instances flip), instance
+// cull-disable / force-non-opaque flags, any-hit for MASK instances, accept-first-hit occlusion rays, and
+// the alpha-shadow transmittance product.
 #pragma once
 #include "pt_shading.h"
 
@@ -38,6 +42,8 @@ PT_DEV void candidate_alpha(const SceneRec& sc, uint32_t inst, uint32_t prim, fl
     cutoff = m.alpha_cutoff;
 }
 
+#define PT_CSWAP(a, b) { uint32_t _lo = min(a, b), _hi = max(a, b); a = _lo; b = _hi; }
+
 // mode 0: closest hit (hit group 0).  mode 1: occlusion / shadow (hit group 1), `transmission` is the ShadowPayload.
 // Returns true if a hit was committed.
 template <bool COUNT>
@@ -55,37 +61,43 @@ PT_DEV bool traverse(const SceneRec& sc, int* lds_stack, const Ray& r, uint32_t 
     bool committed = false;
     const float4* nodes = (const float4*)sc.nodes;
     const float4* tris = (const float4*)sc.tris;
+    auto push = [&](int ref) {
+        if (sp < kStackLds) lds_stack[sp * kBlock] = ref;
+        else if (sp < kStackLds + kStackSpill) spill[sp - kStackLds] = ref;
+        else st.overflow++;
+        if (sp < kStackLds + kStackSpill) sp++;
+    };
     for (;;) {
         if (cur >= 0) {
-            const float4* np = nodes + (size_t)cur * 4;
-            float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            const float4* np = nodes + (size_t)cur * 8;
+            const float4 lox = np[0], loy = np[1], loz = np[2], hix = np[3], hiy = np[4], hiz = np[5], chf = np[6];
             if (COUNT) st.nodes++;
-            float limit = all_candidates ? r.tmax : best.t;
-            // child 0: lo (n0.x n0.y n0.z) hi (n0.w n1.x n1.y); child 1: lo (n1.z n1.w n2.x) hi (n2.y n2.z n2.w)
-            float a0 = n0.x * inv.x - ood.x, b0 = n0.w * inv.x - ood.x;
-            float a1 = n0.y * inv.y - ood.y, b1 = n1.x * inv.y - ood.y;
-            float a2 = n0.z * inv.z - ood.z, b2 = n1.y * inv.z - ood.z;
-            float tn0 = fmaxf(fmaxf(fminf(a0, b0), fminf(a1, b1)), fmaxf(fminf(a2, b2), r.tmin));
-            float tx0 = fminf(fminf(fmaxf(a0, b0), fmaxf(a1, b1)), fminf(fmaxf(a2, b2), limit)) * 1.0000004f;
-            float c0 = n1.z * inv.x - ood.x, d0 = n2.y * inv.x - ood.x;
-            float c1 = n1.w * inv.y - ood.y, d1 = n2.z * inv.y - ood.y;
-            float c2 = n2.x * inv.z - ood.z, d2 = n2.w * inv.z - ood.z;
-            float tn1 = fmaxf(fmaxf(fminf(c0, d0), fminf(c1, d1)), fmaxf(fminf(c2, d2), r.tmin));
-            float tx1 = fminf(fminf(fmaxf(c0, d0), fmaxf(c1, d1)), fminf(fmaxf(c2, d2), limit)) * 1.0000004f;
-            bool h0 = tn0 <= tx0, h1 = tn1 <= tx1;
-            int ch0 = __float_as_int(n3.x), ch1 = __float_as_int(n3.y);
-            if (h0 && h1) {
-                bool swap = tn1 < tn0;
-                int nearc = swap ? ch1 : ch0, farc = swap ? ch0 : ch1;
-                if (sp < kStackLds) lds_stack[sp * kBlock] = farc;
-                else if (sp < kStackLds + kStackSpill) spill[sp - kStackLds] = farc;
-                else st.overflow++;
-                if (sp < kStackLds + kStackSpill) sp++;
-                cur = nearc;
+            const float limit = all_candidates ? r.tmax : best.t;
+            const int c0 = __float_as_int(chf.x), c1 = __float_as_int(chf.y), c2 = __float_as_int(chf.z), c3 = __float_as_int(chf.w);
+            uint32_t key[4];
+#define PT_SLAB(K, CH, LX, LY, LZ, HX, HY, HZ)                                                                     \
+    {                                                                                                           \
+        float a0 = LX * inv.x - ood.x, b0 = HX * inv.x - ood.x, a1 = LY * inv.y - ood.y, b1 = HY * inv.y - ood.y; \
+        float a2 = LZ * inv.z - ood.z, b2 = HZ * inv.z - ood.z;                                                  \
+        float tn = fmaxf(fmaxf(fminf(a0, b0), fminf(a1, b1)), fmaxf(fminf(a2, b2), r.tmin));                    \
+        float tx = fminf(fminf(fmaxf(a0, b0), fmaxf(a1, b1)), fminf(fmaxf(a2, b2), limit)) * 1.0000004f;        \
+        key[K] = (tn <= tx && CH != kEmptyChild) ? ((__float_as_uint(tn) & ~3u) | (uint32_t)K) : 0xffffffffu;    \
+    }
+            PT_SLAB(0, c0, lox.x, loy.x, loz.x, hix.x, hiy.x, hiz.x)
+            PT_SLAB(1, c1, lox.y, loy.y, loz.y, hix.y, hiy.y, hiz.y)
+            PT_SLAB(2, c2, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z)
+            PT_SLAB(3, c3, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w)
+#undef PT_SLAB
+            // sort the 4 keys ascending (tn >= 0, so its bit pattern orders like the float); misses sink to the end
+            PT_CSWAP(key[0], key[1]) PT_CSWAP(key[2], key[3]) PT_CSWAP(key[0], key[2]) PT_CSWAP(key[1], key[3]) PT_CSWAP(key[1], key[2])
+            auto child_of = [&](uint32_t k) { uint32_t s = k & 3u; return s == 0 ? c0 : (s == 1 ? c1 : (s == 2 ? c2 : c3)); };
+            if (key[0] != 0xffffffffu) {
+                if (key[3] != 0xffffffffu) push(child_of(key[3]));
+                if (key[2] != 0xffffffffu) push(child_of(key[2]));
+                if (key[1] != 0xffffffffu) push(child_of(key[1]));
+                cur = child_of(key[0]);
                 continue;
             }
-            if (h0) { cur = ch0; continue; }
-            if (h1) { cur = ch1; continue; }
         } else {
             const float4* tp = tris + (size_t)(~cur) * 3;
             float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];

@@ -41,6 +41,17 @@ struct __attribute__((aligned(64))) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode");
 
+// 128-B 4-wide node (two 64-B lines, SoA per axis so one dwordx4 load feeds four slab tests): built by collapsing
+// every other level of the LBVH.  child >= 0: wide node index; child < 0: leaf ~triangle index; kEmptyChild: unused
+// slot (its box is lo = +inf, hi = -inf and can never be hit).
+struct __attribute__((aligned(128))) Bvh4Node {
+    float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+    int32_t child[4];
+    uint32_t _pad[4];
+};
+static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node");
+constexpr int32_t kEmptyChild = 0x7fffffff;
+
 // 48-B triangle packet in world space: v0, e1 = v1-v0, e2 = v2-v0 + ids.
 struct __attribute__((aligned(16))) TriPacket {
     float v0[3]; uint32_t inst;
@@ -67,9 +78,9 @@ struct SceneRec {
     const pt_material* materials;
     const pt_light* lights;
     const InstanceRec* instances;
-    const BvhNode* nodes;
+    const Bvh4Node* nodes;
     const TriPacket* tris;
-    int32_t root;               // node index, or ~0 when the scene is a single triangle
+    int32_t root;               // wide node index (0), or ~0 when the scene is a single triangle
     uint32_t num_tris;
     const float* sheen_e;       // 16x16
     const float* srgb_lut;      // 256

@@ -304,7 +304,7 @@ typedef struct pt_tonemap_config {
 typedef struct pt_stats {
     uint64_t rays;              /* traversals started since pt_reset_stats (all kinds) */
     uint64_t rays_primary, rays_bounce, rays_shadow;
-    uint64_t nodes_visited;     /* 64-B BVH nodes fetched (0 unless counters enabled) */
+    uint64_t nodes_visited;     /* 128-B 4-wide BVH nodes fetched (0 unless counters enabled) */
     uint64_t tris_tested;       /* 48-B triangle packets fetched (0 unless counters enabled) */
     uint64_t closest_hits;      /* shading invocations */
     uint64_t texture_taps;      /* bilinear footprints fetched in shading */
