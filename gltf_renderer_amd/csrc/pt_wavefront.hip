@@ -41,7 +41,8 @@ struct WfBuffers {
     // shadow queue, kShards segments of 2 * seg_cap entries: (o.xyz, bits: slot | is_light << 31), (d.xyz, tmax)
     float4* sh_o;
     float4* sh_d;
-    uint32_t* cnt[3];     // per-shard entry counts: closest queue 0, closest queue 1, shadow queue (stride kCounterStride)
+    uint32_t* cnt[5];     // per shard (stride kCounterStride): entry counts of closest queue 0, closest queue 1, shadow queue;
+                          // [3], [4]: dynamic-fetch heads of the closest / shadow trace stages
     uint32_t capacity;    // slots
     uint32_t seg_cap;     // entries per closest-queue segment
     uint32_t blocks_per_shard;
@@ -100,26 +101,89 @@ __global__ __launch_bounds__(kBlock) void k_wf_generate(FrameConstants fc, WfBuf
     flush_counters(counters, threadIdx.x & 63, n_primary, 0, 0, 0, st);
 }
 
-// closest-hit traversal of queue `cur`; member 0 of each shard also zeroes the counters the following shade stage fills.
+// Wave-persistent "while-while" traversal of one shard segment with dynamic ray fetch (pt_traverse.h).
+// MODE 0: closest hits of queue `cur` -> wf.hit.  MODE 1: occlusion of the shadow queue -> pend_*.w.
+#ifndef PT_REFILL
+#define PT_REFILL 24          // idle lanes that trigger a refill from the shard queue
+#endif
+template <bool COUNT, int MODE>
+PT_DEV void trace_persistent(const SceneRec& sc, const WfBuffers& wf, int* my_stack, const ShardView& sv, int cur, uint32_t rf_closest, uint32_t rmask,
+                             uint32_t flags, LaneStats& st) {
+    const uint32_t n = wf.cnt[MODE == 0 ? cur : 2][sv.shard * kCounterStride];
+    uint32_t* head = wf.cnt[MODE == 0 ? 3 : 4] + sv.shard * kCounterStride;
+    const size_t base = MODE == 0 ? (size_t)sv.shard * wf.seg_cap : (size_t)sv.shard * wf.seg_cap * 2;
+    const uint32_t lane = threadIdx.x & 63;
+    int spill[kStackSpill];
+    Trav t;
+    t.cur = kTravDone; t.sp = 0;
+    bool has = false, exhausted = (n == 0);
+    uint32_t entry = 0, slot_bits = 0;
+    for (;;) {
+        // ---- refill idle lanes from the shard queue: ballot + one atomic per wave
+        const unsigned long long idle = __ballot(!has);
+        const uint32_t nidle = (uint32_t)__popcll(idle);
+        if (!exhausted && nidle >= PT_REFILL) {
+            const int leader = __ffsll((long long)idle) - 1;
+            uint32_t first = 0;
+            if ((int)lane == leader) first = atomicAdd(head, nidle);
+            first = __shfl(first, leader, 64);
+            if (!has) {
+                const uint32_t i = first + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (i < n) {
+                    Ray ray;
+                    if (MODE == 0) {
+                        const float4 o = wf.ray_o[cur][base + i], d = wf.ray_d[cur][base + i];
+                        ray.o = v3(o.x, o.y, o.z); ray.tmin = 0; ray.d = v3(d.x, d.y, d.z); ray.tmax = o.w;
+                        trav_init(t, sc, ray, rf_closest, rmask, 0, 0.0f);
+                    } else {
+                        const float4 o = wf.sh_o[base + i], d = wf.sh_d[base + i];
+                        slot_bits = __float_as_uint(o.w);
+                        ray.o = v3(o.x, o.y, o.z); ray.tmin = 0; ray.d = v3(d.x, d.y, d.z); ray.tmax = d.w;
+                        const bool alpha_shadow = (slot_bits >> 31) && (flags & PT_FLAG_ALPHA_SHADOWS);          // TraceShadowRay :724-742
+                        uint32_t srf = (flags & PT_FLAG_CULL_BACKFACE) ? RF_CULL_BACK : 0;
+                        srf |= alpha_shadow ? RF_FORCE_NON_OPAQUE : RF_ACCEPT_FIRST;
+                        trav_init(t, sc, ray, srf, 0xff, 1, alpha_shadow ? 1.0f : 0.0f);
+                    }
+                    entry = i;
+                    has = true;
+                }
+            }
+            if (first + nidle >= n) exhausted = true;
+        }
+        if (__ballot(has) == 0) {
+            if (exhausted) break;
+            continue;                                       // cannot happen (all idle -> nidle = 64 >= PT_REFILL), kept for safety
+        }
+        // ---- node phase: every lane that holds an inner node steps until none does
+        while (__ballot(has && t.cur >= 0)) {
+            if (has && t.cur >= 0) trav_node_step<COUNT>(t, sc, my_stack, spill, st);
+        }
+        // ---- leaf phase
+        if (has && t.cur != kTravDone) trav_leaf_step<COUNT>(t, sc, my_stack, spill, st);
+        // ---- retire finished rays
+        if (has && t.cur == kTravDone) {
+            if (MODE == 0) {
+                const uint32_t bits = t.committed ? ((uint32_t)t.best.tri | (t.best.front ? 0x80000000u : 0u)) : kMissTri;
+                wf.hit[base + entry] = make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(bits));
+            } else {
+                const float tr = t.committed ? t.transmission : 1.0f;                                              // ShadowMiss :1081-1085
+                const uint32_t slot = slot_bits & 0x7fffffffu;
+                float* w = (slot_bits >> 31) ? &wf.pend_light[slot].w : &wf.pend_env[slot].w;
+                *w = tr;
+            }
+            has = false;
+        }
+    }
+}
+
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_wf_trace(SceneRec sc, WfBuffers wf, int cur, uint32_t rf, uint32_t rmask, Counters* __restrict__ counters) {
     __shared__ int s_stack[kStackLds * kBlock];
-    int* my_stack = s_stack + threadIdx.x;
     const ShardView sv = shard_view(wf);
+    // member 0 of each shard zeroes the counters the following shade stage fills
     if (sv.member == 0 && threadIdx.x == 0) { wf.cnt[cur ^ 1][sv.shard * kCounterStride] = 0; wf.cnt[2][sv.shard * kCounterStride] = 0; }
-    const uint32_t n = wf.cnt[cur][sv.shard * kCounterStride];
-    const size_t base = (size_t)sv.shard * wf.seg_cap;
     LaneStats st = {0, 0, 0, 0};
-    for (uint32_t i = sv.member * kBlock + threadIdx.x; i < n; i += sv.stride) {
-        const float4 o = wf.ray_o[cur][base + i], d = wf.ray_d[cur][base + i];
-        Ray ray;
-        ray.o = v3(o.x, o.y, o.z); ray.tmin = 0; ray.d = v3(d.x, d.y, d.z); ray.tmax = o.w;
-        HitRec hit;
-        float tr = 0;
-        const bool got = traverse<COUNT>(sc, my_stack, ray, rf, rmask, 0, hit, tr, st);
-        const uint32_t bits = got ? ((uint32_t)hit.tri | (hit.front ? 0x80000000u : 0u)) : kMissTri;
-        wf.hit[base + i] = make_float4(hit.t, hit.u, hit.v, __uint_as_float(bits));
-    }
+    trace_persistent<COUNT, 0>(sc, wf, s_stack + threadIdx.x, sv, cur, rf, rmask, 0, st);
     if (COUNT) flush_counters(counters, threadIdx.x & 63, 0, 0, 0, 0, st);
     else if (st.overflow) atomicAdd(&counters->stack_overflow, (unsigned long long)st.overflow);
 }
@@ -142,6 +206,8 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
     const size_t base = (size_t)sv.shard * wf.seg_cap, sbase = (size_t)sv.shard * wf.seg_cap * 2;
     uint32_t* cnt_next = wf.cnt[nxt] + sv.shard * kCounterStride;
     uint32_t* cnt_shadow = wf.cnt[2] + sv.shard * kCounterStride;
+    // the dynamic-fetch heads of both trace stages are idle while shading runs: rewind them here
+    if (sv.member == 0 && threadIdx.x == 0) { wf.cnt[3][sv.shard * kCounterStride] = 0; wf.cnt[4][sv.shard * kCounterStride] = 0; }
     unsigned n_bounce = 0, n_shadow = 0, n_hits = 0;
     LaneStats st = {0, 0, 0, 0};
     const uint32_t rounds = (n + sv.stride - 1) / sv.stride;      // uniform per workgroup: ballots inside stay wave-uniform
@@ -218,29 +284,9 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void k_wf_shadow(SceneRec sc, WfBuffers wf, uint32_t flags, Counters* __restrict__ counters) {
     __shared__ int s_stack[kStackLds * kBlock];
-    int* my_stack = s_stack + threadIdx.x;
     const ShardView sv = shard_view(wf);
-    const uint32_t n = wf.cnt[2][sv.shard * kCounterStride];
-    const size_t sbase = (size_t)sv.shard * wf.seg_cap * 2;
     LaneStats st = {0, 0, 0, 0};
-    for (uint32_t i = sv.member * kBlock + threadIdx.x; i < n; i += sv.stride) {
-        const float4 o = wf.sh_o[sbase + i], d = wf.sh_d[sbase + i];
-        const uint32_t sb = __float_as_uint(o.w);
-        const uint32_t slot = sb & 0x7fffffffu;
-        const bool is_light = (sb >> 31) != 0;
-        Ray ray;
-        ray.o = v3(o.x, o.y, o.z); ray.tmin = 0; ray.d = v3(d.x, d.y, d.z); ray.tmax = d.w;
-        const bool alpha_shadow = is_light && (flags & PT_FLAG_ALPHA_SHADOWS);
-        uint32_t srf = (flags & PT_FLAG_CULL_BACKFACE) ? RF_CULL_BACK : 0;
-        float transmission = 0.0f;
-        if (alpha_shadow) { transmission = 1.0f; srf |= RF_FORCE_NON_OPAQUE; }
-        else srf |= RF_ACCEPT_FIRST;
-        HitRec hit;
-        const bool got = traverse<COUNT>(sc, my_stack, ray, srf, 0xff, 1, hit, transmission, st);
-        if (!got) transmission = 1.0f;                                                               // ShadowMiss :1081-1085
-        float* w = is_light ? &wf.pend_light[slot].w : &wf.pend_env[slot].w;
-        *w = transmission;
-    }
+    trace_persistent<COUNT, 1>(sc, wf, s_stack + threadIdx.x, sv, 0, 0, 0xff, flags, st);
     if (COUNT) flush_counters(counters, threadIdx.x & 63, 0, 0, 0, 0, st);
     else if (st.overflow) atomicAdd(&counters->stack_overflow, (unsigned long long)st.overflow);
 }
@@ -270,7 +316,7 @@ static uint32_t seg_cap_for(uint32_t slots, uint32_t blocks_per_shard) {
 size_t wavefront_workspace_bytes(uint32_t slots, int stage_blocks) {
     const uint32_t bps = blocks_per_shard_for(stage_blocks);
     const size_t q = (size_t)kShards * seg_cap_for(slots, bps);
-    return (size_t)slots * (5 * 16 + 4) + q * (4 * 16 + 16 + 2 * 2 * 16) + 3 * kShards * kCounterStride * 4 + 32 * 256;
+    return (size_t)slots * (5 * 16 + 4) + q * (4 * 16 + 16 + 2 * 2 * 16) + 5 * kShards * kCounterStride * 4 + 32 * 256;
 }
 
 static WfBuffers carve(void* base, uint32_t slots, int stage_blocks) {
@@ -280,7 +326,7 @@ static WfBuffers carve(void* base, uint32_t slots, int stage_blocks) {
     wf.blocks_per_shard = blocks_per_shard_for(stage_blocks);
     wf.seg_cap = seg_cap_for(slots, wf.blocks_per_shard);
     const size_t q = (size_t)kShards * wf.seg_cap;
-    for (int k = 0; k < 3; k++) wf.cnt[k] = (uint32_t*)take((size_t)kShards * kCounterStride * 4);
+    for (int k = 0; k < 5; k++) wf.cnt[k] = (uint32_t*)take((size_t)kShards * kCounterStride * 4);
     wf.L = (float4*)take((size_t)slots * 16);
     wf.beta_pdf = (float4*)take((size_t)slots * 16);
     wf.thr_misc = (float4*)take((size_t)slots * 16);
@@ -300,7 +346,7 @@ hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4
     if (fc.my_tiles == 0) return hipSuccess;
     const uint32_t slots = fc.my_tiles * kBlock;
     WfBuffers wf = carve(workspace, slots, stage_blocks);
-    hipError_t e = hipMemsetAsync(wf.cnt[0], 0, (size_t)3 * kShards * kCounterStride * 4, stream);     // the three counter arrays are contiguous
+    hipError_t e = hipMemsetAsync(wf.cnt[0], 0, (size_t)5 * kShards * kCounterStride * 4, stream);     // the five counter arrays are contiguous
     if (e) return e;
     const dim3 block(kBlock), full(fc.my_tiles), stage(kShards * wf.blocks_per_shard);
     hipLaunchKernelGGL(k_wf_generate, stage, block, 0, stream, fc, wf, counters);
