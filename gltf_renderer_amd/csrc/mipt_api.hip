@@ -57,7 +57,7 @@ struct pt_ctx {
     void* d_bones = nullptr; size_t bones_cap = 0;
     void* d_workspace = nullptr; size_t workspace_cap = 0;     // wavefront ray / hit / path-state arrays
     int kernel_mode = PT_MODE_WAVEFRONT;
-    int stage_blocks = 2048;
+    int stage_blocks = 1536;      // 256 CUs x 6 resident 256-thread workgroups of the trace stages (LDS- and VGPR-limited)
     hipEvent_t ev_trace[2] = {nullptr, nullptr}, ev_accel[2] = {nullptr, nullptr}, ev_skin[2] = {nullptr, nullptr};
     bool have_trace = false, have_accel = false, have_skin = false;
     int bounce_limit = PT_REFERENCE_MAX_BOUNCES;

@@ -80,8 +80,13 @@ PT_DEV uint32_t encode_tangent_space(vec3 normal, vec3 tangent, float winding) {
 
 // ---------------------------------------------------------------- software texture unit
 PT_DEV int wrap_addr(int i, int n, int mode) {
-    if (mode == PT_ADDRESS_WRAP) { int m = i % n; return m < 0 ? m + n : m; }
-    if (mode == PT_ADDRESS_MIRROR) { int p = 2 * n; int m = i % p; if (m < 0) m += p; return m < n ? m : p - 1 - m; }
+    const bool pow2 = (n & (n - 1)) == 0;                  // two's-complement AND is the non-negative modulo (no ~30-instruction idiv)
+    if (mode == PT_ADDRESS_WRAP) { if (pow2) return i & (n - 1); int m = i % n; return m < 0 ? m + n : m; }
+    if (mode == PT_ADDRESS_MIRROR) {
+        int p = 2 * n, m;
+        if (pow2) m = i & (p - 1); else { m = i % p; if (m < 0) m += p; }
+        return m < n ? m : p - 1 - m;
+    }
     return i < 0 ? 0 : (i >= n ? n - 1 : i);
 }
 PT_DEV vec4 unpack_texel(uint32_t t, uint32_t srgb, const float* lut) {
@@ -116,7 +121,8 @@ PT_DEV vec4 sample_texture2d(const TextureRec& t, const SamplerRec& s, const flo
 // TransformUv + SampleTexture (Material.hlsli:68-96): (T*(R*S))*(u,v,1) has rows (c*sx, s*sy, ox), (-s*sx, c*sy, oy).
 PT_DEV vec4 sample_material_texture(const SceneRec& sc, const pt_texture_sample& a, const vec2 tc[2], unsigned& taps) {
     vec2 uv = tc[a.tex_coord & 1];
-    float sn = sinf(a.rotation), cs = cosf(a.rotation);
+    float sn = 0.0f, cs = 1.0f;                            // sin(0) = 0, cos(0) = 1 exactly: skip the argument reduction
+    if (a.rotation != 0.0f) { sn = sinf(a.rotation); cs = cosf(a.rotation); }
     float tu = (cs * a.scale[0]) * uv.x + (sn * a.scale[1]) * uv.y + a.offset[0];
     float tv = (-sn * a.scale[0]) * uv.x + (cs * a.scale[1]) * uv.y + a.offset[1];
     taps++;

@@ -92,7 +92,7 @@ PT_DEV void trav_pop(Trav& t, const int* lds_stack, const int* spill) {
 #define PT_CSWAP(a, b) { uint32_t _lo = min(a, b), _hi = max(a, b); a = _lo; b = _hi; }
 
 // One inner-node step: t.cur >= 0 on entry; on exit t.cur is the nearest hit child, or the popped entry, or kTravDone.
-template <bool COUNT>
+template <bool COUNT, bool ORDERED = true>
 PT_DEV void trav_node_step(Trav& t, const SceneRec& sc, int* lds_stack, int* spill, LaneStats& st) {
     const float4* np = (const float4*)sc.nodes + (size_t)t.cur * 8;
     const float4 lox = np[0], loy = np[1], loz = np[2], hix = np[3], hiy = np[4], hiz = np[5], chf = np[6];
@@ -113,6 +113,16 @@ PT_DEV void trav_node_step(Trav& t, const SceneRec& sc, int* lds_stack, int* spi
     PT_SLAB(2, c2, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z)
     PT_SLAB(3, c3, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w)
 #undef PT_SLAB
+    if (!ORDERED) {
+        // occlusion rays accept any hit: visiting order is irrelevant, skip the sort
+        int next = kTravDone;
+        if (key[0] != 0xffffffffu) next = c0;
+        if (key[1] != 0xffffffffu) { if (next != kTravDone) trav_push(t, lds_stack, spill, c1, st); else next = c1; }
+        if (key[2] != 0xffffffffu) { if (next != kTravDone) trav_push(t, lds_stack, spill, c2, st); else next = c2; }
+        if (key[3] != 0xffffffffu) { if (next != kTravDone) trav_push(t, lds_stack, spill, c3, st); else next = c3; }
+        if (next != kTravDone) t.cur = next; else trav_pop(t, lds_stack, spill);
+        return;
+    }
     // sort the 4 keys ascending (tn >= 0, so its bit pattern orders like the float); misses sink to the end
     PT_CSWAP(key[0], key[1]) PT_CSWAP(key[2], key[3]) PT_CSWAP(key[0], key[2]) PT_CSWAP(key[1], key[3]) PT_CSWAP(key[1], key[2])
     auto child_of = [&](uint32_t k) { uint32_t s = k & 3u; return s == 0 ? c0 : (s == 1 ? c1 : (s == 2 ? c2 : c3)); };

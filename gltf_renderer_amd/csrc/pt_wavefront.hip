@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_generate(FrameConstants fc, WfBuf
 // Wave-persistent "while-while" traversal of one shard segment with dynamic ray fetch (pt_traverse.h).
 // MODE 0: closest hits of queue `cur` -> wf.hit.  MODE 1: occlusion of the shadow queue -> pend_*.w.
 #ifndef PT_REFILL
-#define PT_REFILL 24          // idle lanes that trigger a refill from the shard queue
+#define PT_REFILL 48          // idle lanes that trigger a refill from the shard queue (swept 8..64 on MI355X: 48 is best)
 #endif
 template <bool COUNT, int MODE>
 PT_DEV void trace_persistent(const SceneRec& sc, const WfBuffers& wf, int* my_stack, const ShardView& sv, int cur, uint32_t rf_closest, uint32_t rmask,
@@ -156,7 +156,7 @@ PT_DEV void trace_persistent(const SceneRec& sc, const WfBuffers& wf, int* my_st
         }
         // ---- node phase: every lane that holds an inner node steps until none does
         while (__ballot(has && t.cur >= 0)) {
-            if (has && t.cur >= 0) trav_node_step<COUNT>(t, sc, my_stack, spill, st);
+            if (has && t.cur >= 0) trav_node_step<COUNT, MODE == 0>(t, sc, my_stack, spill, st);
         }
         // ---- leaf phase
         if (has && t.cur != kTravDone) trav_leaf_step<COUNT>(t, sc, my_stack, spill, st);
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_resolve(FrameConstants fc, WfBuff
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
 static uint32_t blocks_per_shard_for(int stage_blocks) {
-    uint32_t b = (uint32_t)(stage_blocks > 0 ? stage_blocks : 2048) / kShards;
+    uint32_t b = (uint32_t)(stage_blocks > 0 ? stage_blocks : 1536) / kShards;
     return b < 1 ? 1 : b;
 }
 static uint32_t seg_cap_for(uint32_t slots, uint32_t blocks_per_shard) {
