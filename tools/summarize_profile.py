@@ -1,79 +1,89 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 CSV output (kernel trace + PMC passes) into small text/JSON files for profiles/."""
+"""Summarise rocprofv3 CSV output (kernel trace + PMC passes of the SAME bench command) into small text / JSON
+files for profiles/.  One "launch" of the hot path = one pt_trace call = all path-tracing kernels of one frame
+(wavefront: k_wf_generate + (k_wf_trace, k_wf_shade, k_wf_shadow) x (max_bounces + 1) + k_wf_resolve;
+megakernel: one pt_megakernel), so per-launch figures are per-frame sums.
+
+usage: summarize_profile.py <dir> <tag> <frames in the PMC runs> [<frames in the trace run>]"""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
 out_dir, tag = sys.argv[1], sys.argv[2]
+pmc_frames = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+trace_frames = int(sys.argv[4]) if len(sys.argv) > 4 else pmc_frames
 
 
 def find(pattern):
     return sorted(glob.glob(os.path.join(out_dir, pattern), recursive=True))
 
 
+def is_pt(name):
+    return "k_wf_" in name or "pt_megakernel" in name
+
+
 summary = {"tag": tag}
 lines = []
-# ---- kernel trace: per-kernel count / total / mean duration
-kt = find("trace/**/*kernel_trace.csv")
 per = defaultdict(list)
-for f in kt:
+for f in find("trace/**/*kernel_trace.csv"):
     for row in csv.DictReader(open(f)):
-        name = row.get("Kernel_Name") or row.get("kernel_name") or ""
         try:
             dur = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
         except Exception:
             continue
-        per[name].append((dur, row.get("VGPR_Count"), row.get("SGPR_Count"), row.get("LDS_Block_Size"), row.get("Scratch_Size"), row.get("Grid_Size"), row.get("Workgroup_Size")))
+        per[row.get("Kernel_Name", "")].append((dur, row.get("VGPR_Count"), row.get("SGPR_Count"), row.get("LDS_Block_Size"), row.get("Scratch_Size")))
 tot = sum(sum(d[0] for d in v) for v in per.values()) or 1
-lines.append("kernel-trace summary (%s): name, calls, total_ms, mean_us, pct, vgpr, sgpr, lds, scratch, grid, wg" % tag)
+lines.append("kernel-trace summary (%s): name | calls | total ms | mean us | %% of GPU time | vgpr sgpr lds scratch" % tag)
 kernels = {}
+pt_total = 0
 for name, v in sorted(per.items(), key=lambda kv: -sum(d[0] for d in kv[1])):
     t = sum(d[0] for d in v)
-    short = name[:90]
-    lines.append("%-90s %6d %10.3f %10.2f %6.2f%%  %s %s %s %s %s %s" % (short, len(v), t / 1e6, t / len(v) / 1e3, 100.0 * t / tot, v[0][1], v[0][2], v[0][3], v[0][4], v[0][5], v[0][6]))
-    kernels[name] = {"calls": len(v), "total_ms": t / 1e6, "mean_us": t / len(v) / 1e3}
-summary["kernels"] = {k[:120]: v for k, v in kernels.items()}
-# ---- PMC passes
-def pmc(sub, counters):
-    res = defaultdict(lambda: defaultdict(list))
+    short = name.split("(")[0].replace("void ", "")[:60]
+    lines.append("%-60s %6d %10.3f %10.2f %6.2f%%  %s %s %s %s" % (short, len(v), t / 1e6, t / len(v) / 1e3, 100.0 * t / tot, v[0][1], v[0][2], v[0][3], v[0][4]))
+    kernels[short] = {"calls": len(v), "total_ms": t / 1e6, "mean_us": t / len(v) / 1e3}
+    if is_pt(name):
+        pt_total += t
+summary["kernels"] = kernels
+summary["pt_kernel_ms_per_frame"] = pt_total / 1e6 / max(trace_frames, 1)
+lines.append("path-tracing kernels: %.3f ms per frame (sum over %d frames / %d)" % (summary["pt_kernel_ms_per_frame"], trace_frames, trace_frames))
+
+
+def pmc_total(sub, counters):
+    res = defaultdict(float)
     for f in find(sub + "/**/*counter_collection.csv"):
         for row in csv.DictReader(open(f)):
-            name = row.get("Kernel_Name") or ""
-            c = row.get("Counter_Name")
-            if c in counters:
-                res[name][c].append(float(row["Counter_Value"]))
+            if is_pt(row.get("Kernel_Name", "")) and row.get("Counter_Name") in counters:
+                res[row["Counter_Name"]] += float(row["Counter_Value"])
     return res
-mk = None
-for name in per:
-    if "pt_megakernel" in name:
-        mk = name
+
+
+p = {}
 for sub, cs in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]), ("pmc_l2", ["TCC_HIT_sum", "TCC_MISS_sum"])):
-    res = pmc(sub, cs)
-    for name, d in res.items():
-        if "pt_megakernel" not in name:
-            continue
-        for c, vals in d.items():
-            # skip warm-up launches: use the last `steps` launches
-            lines.append("PMC %-14s %-40s launches %d mean %.4g (last 10 mean %.4g)" % (c, name[:40], len(vals), sum(vals) / len(vals), sum(vals[-10:]) / len(vals[-10:])))
-            summary.setdefault("pmc", {})[c] = sum(vals[-10:]) / len(vals[-10:])
-p = summary.get("pmc", {})
+    for c, v in pmc_total(sub, cs).items():
+        p[c] = v / max(pmc_frames, 1)
+        lines.append("PMC %-14s per frame (sum over path-tracing kernels, %d frames): %.5g" % (c, pmc_frames, p[c]))
+summary["pmc_per_frame"] = p
 if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
     raw = (p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024.0
     corrected = (2.0 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024.0
     summary["hbm_bytes_per_launch_raw"] = raw
-    # gfx950: FETCH_SIZE reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM section); this kernel's loads are
-    # scattered 16-B (dwordx4) gathers, an uncalibrated pattern: both figures are kept, the x2-corrected one is the upper bound.
+    # gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section).  These kernels
+    # mostly issue scattered 16-B (dwordx4) gathers, an uncalibrated pattern: both figures are kept; the x2-corrected one is
+    # the upper bound and is what bench.py reports as roofline.traffic.
     summary["hbm_bytes_per_launch"] = corrected
-    lines.append("HBM bytes / pt_megakernel launch: raw (FETCH+WRITE)*1024 = %.4g, with gfx950 FETCH_SIZE x2 correction = %.4g" % (raw, corrected))
+    lines.append("HBM bytes per frame: raw (FETCH+WRITE)*1024 = %.4g ; with the gfx950 FETCH_SIZE x2 correction = %.4g" % (raw, corrected))
 if "TCC_HIT_sum" in p and "TCC_MISS_sum" in p:
     hr = p["TCC_HIT_sum"] / max(p["TCC_HIT_sum"] + p["TCC_MISS_sum"], 1)
     summary["l2_hit_rate"] = hr
-    lines.append("L2 hit rate pt_megakernel: %.4f" % hr)
-for f in ("bench_trace.log",):
-    fp = os.path.join(out_dir, f)
-    if os.path.exists(fp):
-        last = [l for l in open(fp).read().splitlines() if l.startswith("{")]
-        if last:
-            lines.append("bench line under the profiler: " + last[-1])
+    lines.append("L2 hit rate (path-tracing kernels): %.4f" % hr)
+fp = os.path.join(out_dir, "bench_trace.log")
+if os.path.exists(fp):
+    last = [l for l in open(fp).read().splitlines() if l.startswith("{")]
+    if last:
+        lines.append("bench line under the profiler: " + last[-1])
+        try:
+            summary["bench"] = json.loads(last[-1])
+        except Exception:
+            pass
 open(os.path.join(out_dir, "summary.txt"), "w").write("\n".join(lines) + "\n")
 json.dump(summary, open(os.path.join(out_dir, "summary.json"), "w"), indent=1)
 print("\n".join(lines))
