@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--save-image", default="")
     ap.add_argument("--mode", default="wavefront", choices=["wavefront", "megakernel"])
     ap.add_argument("--stage-blocks", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --single-device rehearses N ranks on a 1-GPU box")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (RCCL needs one device per rank)")
     args = ap.parse_args()
 
     import numpy as np
@@ -56,8 +58,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.single_device:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
@@ -89,6 +96,15 @@ def main():
     accel_ms = r.stats().accel_ms
     t_setup = time.time() - t_setup
 
+    def reduce_image(img):
+        if args.backend == "gloo":          # rehearsal path: gloo reduces host tensors
+            host = img.cpu()
+            reduce_frame(host, world)
+            if rank == 0:
+                img.copy_(host)
+        else:
+            reduce_frame(img, world)        # one RCCL reduce(sum) of the accumulation buffer over xGMI
+
     def step(frame):
         if world > 1:
             out.zero_()
@@ -96,7 +112,7 @@ def main():
         p = s.execute_params(frame=frame, tile_rank=rank, tile_rank_count=world, env_handle=h["env"])
         r.trace(settings, p, out)
         if world > 1:
-            reduce_frame(out, world)
+            reduce_image(out)
 
     def sync_all():
         if world > 1:
@@ -120,15 +136,16 @@ def main():
         r.trace(settings, p, out)
         ev[k][1].record()
         if world > 1:
-            reduce_frame(out, world)
+            reduce_image(out)
     sync_all()
     elapsed = time.perf_counter() - t0
     st = r.stats()
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     rays_local = int(st.rays)
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    ry = torch.tensor([rays_local], dtype=torch.float64, device="cuda")
+    stat_dev = "cuda" if args.backend == "nccl" else "cpu"
+    el = torch.tensor([elapsed], dtype=torch.float64, device=stat_dev)
+    ry = torch.tensor([rays_local], dtype=torch.float64, device=stat_dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(ry, op=dist.ReduceOp.SUM)

@@ -352,7 +352,7 @@ def helmet_class(width=1920, height=1080, subdiv=6, tex=2048, seed=2):
 
 
 # ---- config 3: "Sponza-class" --------------------------------------------------------------------------
-def sponza_class(width=1920, height=1080, tex=1024, detail=1.09, seed=3, n_textures=40):
+def sponza_class(width=1920, height=1080, tex=1024, detail=1.083, seed=3, n_textures=40):
     """BASELINE config 3 stand-in for Sponza: an atrium, ~262 k triangles in ~100 primitives (tessellated
     floor, two storeys of box columns with arches, walls, ceiling beams, hanging cloth quads), 25
     materials, ~40 1024^2 textures, 10 MASK-mode foliage quads, 4 point + 1 spot + 1 directional light,
