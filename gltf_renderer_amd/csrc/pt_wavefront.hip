@@ -155,11 +155,18 @@ PT_DEV void trace_persistent(const SceneRec& sc, const WfBuffers& wf, int* my_st
             continue;                                       // cannot happen (all idle -> nidle = 64 >= PT_REFILL), kept for safety
         }
         // ---- node phase: every lane that holds an inner node steps until none does
-        while (__ballot(has && t.cur >= 0)) {
+#ifndef PT_NODE_MIN
+#define PT_NODE_MIN 8         // leave the node phase early when fewer lanes than this hold an inner node AND some lane waits at a leaf
+                              // (swept 1/4/8/12/16/32 on MI355X: 2195/2326/2359/2360/2356/2294 Mrays/s)
+#endif
+        for (;;) {
+            const unsigned long long at_node = __ballot(has && t.cur >= 0);
+            if (at_node == 0) break;
+            if (PT_NODE_MIN > 1 && (int)__popcll(at_node) < PT_NODE_MIN && __ballot(has && t.cur < 0 && t.cur != kTravDone) != 0) break;
             if (has && t.cur >= 0) trav_node_step<COUNT, MODE == 0>(t, sc, my_stack, spill, st);
         }
         // ---- leaf phase
-        if (has && t.cur != kTravDone) trav_leaf_step<COUNT>(t, sc, my_stack, spill, st);
+        if (has && t.cur != kTravDone && t.cur < 0) trav_leaf_step<COUNT>(t, sc, my_stack, spill, st);
         // ---- retire finished rays
         if (has && t.cur == kTravDone) {
             if (MODE == 0) {
@@ -176,8 +183,11 @@ PT_DEV void trace_persistent(const SceneRec& sc, const WfBuffers& wf, int* my_st
     }
 }
 
+#ifndef PT_TRACE_WAVES
+#define PT_TRACE_WAVES 1
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_wf_trace(SceneRec sc, WfBuffers wf, int cur, uint32_t rf, uint32_t rmask, Counters* __restrict__ counters) {
+__global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_trace(SceneRec sc, WfBuffers wf, int cur, uint32_t rf, uint32_t rmask, Counters* __restrict__ counters) {
     __shared__ int s_stack[kStackLds * kBlock];
     const ShardView sv = shard_view(wf);
     // member 0 of each shard zeroes the counters the following shade stage fills
@@ -282,7 +292,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
 
 // occlusion traversal of the shadow queue (TraceShadowRay :724-742); writes the transmission next to its pending term.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_wf_shadow(SceneRec sc, WfBuffers wf, uint32_t flags, Counters* __restrict__ counters) {
+__global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_shadow(SceneRec sc, WfBuffers wf, uint32_t flags, Counters* __restrict__ counters) {
     __shared__ int s_stack[kStackLds * kBlock];
     const ShardView sv = shard_view(wf);
     LaneStats st = {0, 0, 0, 0};
