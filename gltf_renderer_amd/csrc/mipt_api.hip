@@ -31,14 +31,12 @@ struct pt_ctx {
     std::vector<BufferRec> buffers;
     std::vector<TextureRec> textures;
     std::vector<SamplerRec> samplers;
-    BufferRec* d_buffers = nullptr; size_t d_buffers_cap = 0; bool buffers_dirty = true;
-    TextureRec* d_textures = nullptr; size_t d_textures_cap = 0; bool textures_dirty = true;
-    SamplerRec* d_samplers = nullptr; size_t d_samplers_cap = 0; bool samplers_dirty = true;
+    BufferRec* d_buffers = nullptr; size_t d_buffers_cap = 0; bool buffers_dirty = true;   // device copy: BVH build only
+    uint32_t* d_white = nullptr;                                   // 1x1 white texel behind every unbound material slot
 
     // ---- per-frame arrays (Renderer::GatherMaterials / GatherLights)
-    pt_material* d_materials = nullptr; int n_materials = 0; size_t materials_cap = 0;
+    RMat* d_rmats = nullptr; int n_materials = 0; size_t rmats_cap = 0;    // resolved on the host in pt_scene_set_materials
     pt_light* d_lights = nullptr; int n_lights = 0; size_t lights_cap = 0;
-    std::vector<pt_material> h_materials;
 
     // ---- instance table + acceleration structure
     std::vector<InstanceRec> instances;
@@ -189,14 +187,10 @@ public:
             if (ep->environment_map >= (int)ctx->envs.size()) return ctx->fail(PT_ERR_BAD_HANDLE, "bad environment map handle");
             if (!ep->output) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "output is null");
             if (ctx->accel_dirty) { int r = BuildAccel(ctx); if (r) return r; }
-            if (ctx->textures_dirty) { HIPOK(upload_table(ctx->d_textures, ctx->d_textures_cap, ctx->textures, ctx->stream)); ctx->textures_dirty = false; }
-            if (ctx->samplers_dirty) { HIPOK(upload_table(ctx->d_samplers, ctx->d_samplers_cap, ctx->samplers, ctx->stream)); ctx->samplers_dirty = false; }
-            if (ctx->buffers_dirty) { HIPOK(upload_table(ctx->d_buffers, ctx->d_buffers_cap, ctx->buffers, ctx->stream)); ctx->buffers_dirty = false; }
 
             SceneRec sc;
             memset(&sc, 0, sizeof(sc));
-            sc.buffers = ctx->d_buffers; sc.textures = ctx->d_textures; sc.samplers = ctx->d_samplers;
-            sc.materials = ctx->d_materials; sc.lights = ctx->d_lights; sc.instances = ctx->d_instances;
+            sc.rmats = ctx->d_rmats; sc.lights = ctx->d_lights; sc.instances = ctx->d_instances;
             sc.nodes = ctx->d_nodes; sc.tris = ctx->d_tris; sc.root = ctx->root; sc.num_tris = ctx->n_tris;
             sc.sheen_e = ctx->d_sheen; sc.srgb_lut = ctx->d_srgb;
             sc.has_env = 0;
@@ -353,7 +347,8 @@ int pt_create(int device, void* hip_stream, const float* sheen_e_16x16, pt_ctx**
         srgb[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
     }
     bool ok = hipMalloc((void**)&ctx->d_sheen, 256 * 4) == hipSuccess && hipMalloc((void**)&ctx->d_srgb, 256 * 4) == hipSuccess &&
-              hipMalloc((void**)&ctx->d_counters, sizeof(Counters)) == hipSuccess &&
+              hipMalloc((void**)&ctx->d_counters, sizeof(Counters)) == hipSuccess && hipMalloc((void**)&ctx->d_white, 16) == hipSuccess &&
+              hipMemset(ctx->d_white, 0xff, 16) == hipSuccess &&
               hipMemcpy(ctx->d_sheen, sheen_e_16x16, 256 * 4, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(ctx->d_srgb, srgb, 256 * 4, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemset(ctx->d_counters, 0, sizeof(Counters)) == hipSuccess;
@@ -372,7 +367,7 @@ void pt_destroy(pt_ctx* ctx) {
     for (auto& b : ctx->buffers) hipFree((void*)b.ptr);
     for (auto& t : ctx->textures) hipFree((void*)t.texels);
     for (auto* e : ctx->envs) { env_free(*e); delete e; }
-    hipFree(ctx->d_buffers); hipFree(ctx->d_textures); hipFree(ctx->d_samplers); hipFree(ctx->d_materials); hipFree(ctx->d_lights);
+    hipFree(ctx->d_buffers); hipFree(ctx->d_white); hipFree(ctx->d_rmats); hipFree(ctx->d_lights);
     hipFree(ctx->d_instances); hipFree(ctx->d_nodes); hipFree(ctx->d_tris); hipFree(ctx->d_sheen); hipFree(ctx->d_srgb); hipFree(ctx->d_counters);
     accel_scratch_free(ctx->scratch);
     hipFree(ctx->d_bones);
@@ -424,7 +419,6 @@ int pt_texture_create(pt_ctx* ctx, const uint8_t* rgba8, int width, int height, 
     HIPOK(hipMalloc(&d, bytes));
     HIPOK(hipMemcpy(d, rgba8, bytes, hipMemcpyHostToDevice));
     ctx->textures.push_back({(const uint32_t*)d, width, height, srgb ? 1u : 0u, 0u});
-    ctx->textures_dirty = true;
     *handle_out = (int)ctx->textures.size() - 1;
     return PT_OK;
 }
@@ -433,7 +427,6 @@ int pt_sampler_create(pt_ctx* ctx, const pt_sampler_desc* d, int* handle_out) {
     if (!ctx || !d || !handle_out) return PT_ERR_INVALID_ARGUMENT;
     if (d->address_u < 0 || d->address_u > 2 || d->address_v < 0 || d->address_v > 2) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "pt_sampler_create: address mode");
     ctx->samplers.push_back({d->address_u, d->address_v, d->min_filter, d->mag_filter});
-    ctx->samplers_dirty = true;
     *handle_out = (int)ctx->samplers.size() - 1;
     return PT_OK;
 }
@@ -449,8 +442,46 @@ int pt_scene_set_materials(pt_ctx* ctx, const pt_material* m, int count) {
             if (s->sampler < 0 || s->sampler >= (int)ctx->samplers.size()) return ctx->fail(PT_ERR_BAD_HANDLE, "material sampler out of range");
         }
     }
-    ctx->h_materials.assign(m, m + count);
-    HIPOK(upload_table(ctx->d_materials, ctx->materials_cap, ctx->h_materials, ctx->stream));
+    // Resolve every material into the kernel-side record (pt_types.h RMat): descriptor/sampler indices become pointers and
+    // packed flags, the UV transform T*(R*S) (Material.hlsli:68-88) is multiplied out once in fp32.
+    std::vector<RMat> rm((size_t)count);
+    for (int i = 0; i < count; i++) {
+        const pt_material& s = m[i];
+        RMat& r = rm[i];
+        memset(&r, 0, sizeof(r));
+        r.flags = s.flags; r.alpha_mode = s.alpha_mode; r.metalness_factor = s.metalness_factor; r.roughness_factor = s.roughness_factor;
+        memcpy(r.base_color_factor, s.base_color_factor, 16);
+        memcpy(r.emissive_factor, s.emissive_factor, 12); r.alpha_cutoff = s.alpha_cutoff;
+        r.ior = s.ior; r.normal_scale = s.normal_scale; r.specular_factor = s.specular_factor; r.clearcoat_normal_scale = s.clearcoat_normal_scale;
+        memcpy(r.specular_color_factor, s.specular_color_factor, 12); r.clearcoat_factor = s.clearcoat_factor;
+        r.clearcoat_roughness_factor = s.clearcoat_roughness_factor; r.anisotropy_strength = s.anisotropy_strength;
+        r.anisotropy_cos = cosf(s.anisotropy_rotation); r.anisotropy_sin = sinf(s.anisotropy_rotation);
+        memcpy(r.sheen_color_factor, s.sheen_color_factor, 12); r.sheen_roughness_factor = s.sheen_roughness_factor;
+        r.transmission_factor = s.transmission_factor;
+        const pt_texture_sample* slots[SLOT_COUNT] = {&s.normal, &s.albedo, &s.metallic_roughness, &s.occlusion, &s.emissive, &s.specular,
+                                                      &s.specular_color, &s.clearcoat, &s.clearcoat_roughness, &s.clearcoat_normal, &s.anisotropy,
+                                                      &s.sheen_color, &s.sheen_roughness, &s.transmission, &s.thickness};
+        for (int k = 0; k < SLOT_COUNT; k++) {
+            const pt_texture_sample& a = *slots[k];
+            RTex& t = r.tex[k];
+            if (a.descriptor == -1) {                     // unbound: a 1x1 white texel keeps the batched fetch branch-free
+                t.texels = ctx->d_white; t.width = 1; t.height = 1; t.flags = RT_POINT;
+                t.m00 = 0; t.m01 = 0; t.ox = 0; t.m10 = 0; t.m11 = 0; t.oy = 0;
+                continue;
+            }
+            const TextureRec& tx = ctx->textures[a.descriptor];
+            const SamplerRec& sm = ctx->samplers[a.sampler];
+            float sn = 0.0f, cs = 1.0f;                   // sin(0) = 0, cos(0) = 1 exactly
+            if (a.rotation != 0.0f) { sn = sinf(a.rotation); cs = cosf(a.rotation); }
+            t.texels = tx.texels; t.width = tx.width; t.height = tx.height;
+            t.flags = (tx.srgb ? RT_SRGB : 0u) | ((uint32_t)sm.address_u << 1) | ((uint32_t)sm.address_v << 3) |
+                      (sm.mag_filter == PT_FILTER_POINT ? RT_POINT : 0u) | ((a.tex_coord & 1) ? RT_TEXCOORD1 : 0u);
+            t.m00 = cs * a.scale[0]; t.m01 = sn * a.scale[1]; t.ox = a.offset[0];
+            t.m10 = -sn * a.scale[0]; t.m11 = cs * a.scale[1]; t.oy = a.offset[1];
+            r.bound_mask |= 1u << k;
+        }
+    }
+    HIPOK(upload_table(ctx->d_rmats, ctx->rmats_cap, rm, ctx->stream));
     ctx->n_materials = count;
     return PT_OK;
 }
@@ -496,6 +527,14 @@ int pt_scene_set_instances(pt_ctx* ctx, const pt_instance_desc* in, int count) {
                      (double)M[8] * ((double)M[1] * M[6] - (double)M[5] * M[2]);
         r.mask_flags = (d.instance_mask & 0xffu) | ((d.instance_flags & PT_INSTANCE_FLAG_TRIANGLE_CULL_DISABLE) ? TF_CULL_DISABLE : 0u) |
                        ((d.instance_flags & PT_INSTANCE_FLAG_FORCE_NON_OPAQUE) ? TF_FORCE_NON_OPAQUE : 0u) | (det < 0 ? TF_MIRRORED : 0u);
+        auto ptr_of = [&](int h) -> const void* { return h == -1 ? nullptr : ctx->buffers[h].ptr; };
+        r.p_index = ptr_of(g.index_descriptor);
+        r.index_is16 = g.index_descriptor != -1 && ctx->buffers[g.index_descriptor].format == PT_FORMAT_R16_UINT;
+        r.p_position = (const float*)ptr_of(g.position_descriptor);
+        r.p_tangent_space = (const uint32_t*)ptr_of(g.tangent_space_descriptor);
+        r.p_texcoord[0] = (const float2*)ptr_of(g.texcoord_descriptors[0]);
+        r.p_texcoord[1] = (const float2*)ptr_of(g.texcoord_descriptors[1]);
+        r.p_color = (const uint2*)ptr_of(g.color_descriptor);
         r.tri_offset = (uint32_t)tris;
         r.tri_count = d.num_of_indices / 3;
         tris += r.tri_count;

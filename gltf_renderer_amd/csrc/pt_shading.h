@@ -98,72 +98,78 @@ PT_DEV float finite_coord(float x) {
     if (!(x == x) || isinf(x)) return 0.f;
     return clampf(x, -1.0e9f, 1.0e9f);
 }
-// Texture2D.SampleLevel(sampler, uv, 0) on an RGBA8 (optionally sRGB) texture: D3D texel-centre rule,
-// sRGB decoded before filtering, fp32 weights.
-PT_DEV vec4 sample_texture2d(const TextureRec& t, const SamplerRec& s, const float* srgb_lut, float u, float v) {
-    float x = finite_coord(u * (float)t.width), y = finite_coord(v * (float)t.height);
-    if (s.mag_filter == PT_FILTER_POINT) {
-        int i = wrap_addr((int)floorf(x), t.width, s.address_u), j = wrap_addr((int)floorf(y), t.height, s.address_v);
-        return unpack_texel(t.texels[(size_t)j * t.width + i], t.srgb, srgb_lut);
+PT_DEV RTex load_rtex(const RTex* p) {                      // 3 x dwordx4, issued together
+    const float4* q = (const float4*)p;
+    const float4 a = q[0], b = q[1], c = q[2];
+    RTex t;
+    t.texels = (const uint32_t*)(((uint64_t)__float_as_uint(a.y) << 32) | (uint64_t)__float_as_uint(a.x));
+    t.width = __float_as_int(a.z); t.height = __float_as_int(a.w);
+    t.flags = __float_as_uint(b.x); t.m00 = b.y; t.m01 = b.z; t.ox = b.w;
+    t.m10 = c.x; t.m11 = c.y; t.oy = c.z; t._pad = 0;
+    return t;
+}
+// The four texel addresses + weights of one Texture2D.SampleLevel(sampler, uv, 0): D3D texel-centre rule.
+// TransformUv (Material.hlsli:68-88) is folded in: rows (c*sx, s*sy, ox), (-s*sx, c*sy, oy) were formed on the host in fp32.
+struct TexTaps { const uint32_t *p00, *p10, *p01, *p11; float w00, w10, w01, w11; uint32_t srgb; };
+PT_DEV TexTaps texture_taps(const RTex& t, const vec2 tc[2]) {
+    const vec2 uv = (t.flags & RT_TEXCOORD1) ? tc[1] : tc[0];
+    const float tu = t.m00 * uv.x + t.m01 * uv.y + t.ox;
+    const float tv = t.m10 * uv.x + t.m11 * uv.y + t.oy;
+    const int au = (int)((t.flags >> 1) & 3u), av = (int)((t.flags >> 3) & 3u);
+    float x = finite_coord(tu * (float)t.width), y = finite_coord(tv * (float)t.height);
+    TexTaps k;
+    k.srgb = t.flags & RT_SRGB;
+    if (t.flags & RT_POINT) {
+        int i = wrap_addr((int)floorf(x), t.width, au), j = wrap_addr((int)floorf(y), t.height, av);
+        k.p00 = k.p10 = k.p01 = k.p11 = t.texels + (size_t)j * t.width + i;
+        k.w00 = 1; k.w10 = k.w01 = k.w11 = 0;
+        return k;
     }
     x -= 0.5f; y -= 0.5f;
     float fx0 = floorf(x), fy0 = floorf(y);
     float fx = x - fx0, fy = y - fy0;
-    int i0 = wrap_addr((int)fx0, t.width, s.address_u), i1 = wrap_addr((int)fx0 + 1, t.width, s.address_u);
-    int j0 = wrap_addr((int)fy0, t.height, s.address_v), j1 = wrap_addr((int)fy0 + 1, t.height, s.address_v);
+    int i0 = wrap_addr((int)fx0, t.width, au), i1 = wrap_addr((int)fx0 + 1, t.width, au);
+    int j0 = wrap_addr((int)fy0, t.height, av), j1 = wrap_addr((int)fy0 + 1, t.height, av);
     const uint32_t* r0 = t.texels + (size_t)j0 * t.width;
     const uint32_t* r1 = t.texels + (size_t)j1 * t.width;
-    uint32_t t00 = r0[i0], t10 = r0[i1], t01 = r1[i0], t11 = r1[i1];
-    float w00 = (1 - fx) * (1 - fy), w10 = fx * (1 - fy), w01 = (1 - fx) * fy, w11 = fx * fy;
-    return unpack_texel(t00, t.srgb, srgb_lut) * w00 + unpack_texel(t10, t.srgb, srgb_lut) * w10 +
-           unpack_texel(t01, t.srgb, srgb_lut) * w01 + unpack_texel(t11, t.srgb, srgb_lut) * w11;
+    k.p00 = r0 + i0; k.p10 = r0 + i1; k.p01 = r1 + i0; k.p11 = r1 + i1;
+    k.w00 = (1 - fx) * (1 - fy); k.w10 = fx * (1 - fy); k.w01 = (1 - fx) * fy; k.w11 = fx * fy;
+    return k;
 }
-// TransformUv + SampleTexture (Material.hlsli:68-96): (T*(R*S))*(u,v,1) has rows (c*sx, s*sy, ox), (-s*sx, c*sy, oy).
-PT_DEV vec4 sample_material_texture(const SceneRec& sc, const pt_texture_sample& a, const vec2 tc[2], unsigned& taps) {
-    vec2 uv = tc[a.tex_coord & 1];
-    float sn = 0.0f, cs = 1.0f;                            // sin(0) = 0, cos(0) = 1 exactly: skip the argument reduction
-    if (a.rotation != 0.0f) { sn = sinf(a.rotation); cs = cosf(a.rotation); }
-    float tu = (cs * a.scale[0]) * uv.x + (sn * a.scale[1]) * uv.y + a.offset[0];
-    float tv = (-sn * a.scale[0]) * uv.x + (cs * a.scale[1]) * uv.y + a.offset[1];
+PT_DEV vec4 resolve_taps(const TexTaps& k, uint32_t t00, uint32_t t10, uint32_t t01, uint32_t t11, const float* srgb_lut) {
+    if (k.w10 == 0 && k.w01 == 0 && k.w11 == 0 && k.w00 == 1) return unpack_texel(t00, k.srgb, srgb_lut);      // point filter
+    return unpack_texel(t00, k.srgb, srgb_lut) * k.w00 + unpack_texel(t10, k.srgb, srgb_lut) * k.w10 +
+           unpack_texel(t01, k.srgb, srgb_lut) * k.w01 + unpack_texel(t11, k.srgb, srgb_lut) * k.w11;
+}
+// SampleTexture (Material.hlsli:90-96) of one material slot.
+PT_DEV vec4 sample_slot(const SceneRec& sc, const RMat* m, int slot, const vec2 tc[2], unsigned& taps) {
+    const RTex t = load_rtex(&m->tex[slot]);
+    const TexTaps k = texture_taps(t, tc);
     taps++;
-    return sample_texture2d(sc.textures[a.descriptor], sc.samplers[a.sampler], sc.srgb_lut, tu, tv);
+    return resolve_taps(k, *k.p00, *k.p10, *k.p01, *k.p11, sc.srgb_lut);
 }
 
 // ---------------------------------------------------------------- vertex fetch (PathTracer.lib.hlsl:176-302)
-PT_DEV void fetch_indices(const SceneRec& sc, int index_descriptor, uint32_t prim, uint32_t v[3]) {   // :176-184
+PT_DEV void fetch_indices(const InstanceRec& in, uint32_t prim, uint32_t v[3]) {                   // :176-184
     v[0] = prim * 3; v[1] = prim * 3 + 1; v[2] = prim * 3 + 2;
-    if (index_descriptor != -1) {
-        const BufferRec& b = sc.buffers[index_descriptor];
-        if (b.format == PT_FORMAT_R16_UINT) {
-            const uint16_t* p = (const uint16_t*)b.ptr;
+    if (in.p_index) {
+        if (in.index_is16) {
+            const uint16_t* p = (const uint16_t*)in.p_index;
             v[0] = p[v[0]]; v[1] = p[v[1]]; v[2] = p[v[2]];
         } else {
-            const uint32_t* p = (const uint32_t*)b.ptr;
+            const uint32_t* p = (const uint32_t*)in.p_index;
             v[0] = p[v[0]]; v[1] = p[v[1]]; v[2] = p[v[2]];
         }
     }
 }
-PT_DEV vec3 load_pos(const SceneRec& sc, int desc, uint32_t v) {
-    const float* p = (const float*)sc.buffers[desc].ptr + (size_t)v * 3;
-    return {p[0], p[1], p[2]};
+PT_DEV vec4 fetch_vertex_color(const InstanceRec& in, const uint32_t v[3], vec3 w) {                 // :229-242
+    if (!in.p_color) return {1, 1, 1, 1};
+    const uint2 q0 = in.p_color[v[0]], q1 = in.p_color[v[1]], q2 = in.p_color[v[2]];
+    auto un = [](uint2 q) { return vec4{(float)(q.x & 0xffff) / 65535.f, (float)(q.x >> 16) / 65535.f, (float)(q.y & 0xffff) / 65535.f, (float)(q.y >> 16) / 65535.f}; };
+    return un(q0) * w.x + un(q1) * w.y + un(q2) * w.z;
 }
-PT_DEV vec4 fetch_vertex_color(const SceneRec& sc, int desc, const uint32_t v[3], vec3 w) {     // :229-242
-    if (desc == -1) return {1, 1, 1, 1};
-    const uint2* p = (const uint2*)sc.buffers[desc].ptr;
-    vec4 r = {0, 0, 0, 0};
-    float ww[3] = {w.x, w.y, w.z};
-    vec4 c[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        uint2 q = p[v[i]];
-        c[i] = {(float)(q.x & 0xffff) / 65535.f, (float)(q.x >> 16) / 65535.f, (float)(q.y & 0xffff) / 65535.f, (float)(q.y >> 16) / 65535.f};
-    }
-    r = c[0] * ww[0] + c[1] * ww[1] + c[2] * ww[2];
-    return r;
-}
-PT_DEV vec2 fetch_texcoord(const SceneRec& sc, int desc, const uint32_t v[3], vec3 w) {         // :244-257
-    if (desc == -1) return {0, 0};
-    const float2* p = (const float2*)sc.buffers[desc].ptr;
+PT_DEV vec2 fetch_texcoord(const float2* p, const uint32_t v[3], vec3 w) {                           // :244-257
+    if (!p) return {0, 0};
     float2 a = p[v[0]], b = p[v[1]], c = p[v[2]];
     return {w.x * a.x + w.y * b.x + w.z * c.x, w.x * a.y + w.y * b.y + w.z * c.y};
 }
@@ -173,22 +179,30 @@ struct HitGeom {                       // VertexAttributes, PathTracer.lib.hlsl:
     vec4 color;
     vec2 tc[2];
 };
-PT_DEV HitGeom get_vertex_attributes(const SceneRec& sc, const pt_mesh_instance& in, uint32_t prim, vec3 w) {   // :280-302
+PT_DEV HitGeom get_vertex_attributes(const InstanceRec& in, uint32_t prim, vec3 w) {                 // :280-302
     HitGeom a;
     uint32_t v[3];
-    fetch_indices(sc, in.index_descriptor, prim, v);
-    vec3 p0 = load_pos(sc, in.position_descriptor, v[0]), p1 = load_pos(sc, in.position_descriptor, v[1]), p2 = load_pos(sc, in.position_descriptor, v[2]);
+    fetch_indices(in, prim, v);
+    // issue every stream's gathers before using any of them (one memory round trip for all attributes)
+    const float* pp = in.p_position;
+    const float *q0 = pp + (size_t)v[0] * 3, *q1 = pp + (size_t)v[1] * 3, *q2 = pp + (size_t)v[2] * 3;
+    vec3 p0 = v3(q0[0], q0[1], q0[2]), p1 = v3(q1[0], q1[1], q1[2]), p2 = v3(q2[0], q2[1], q2[2]);
+    uint32_t ts0 = 0, ts1 = 0, ts2 = 0;
+    const bool has_ts = in.p_tangent_space != nullptr;
+    if (has_ts) { ts0 = in.p_tangent_space[v[0]]; ts1 = in.p_tangent_space[v[1]]; ts2 = in.p_tangent_space[v[2]]; }
+    a.color = fetch_vertex_color(in, v, w);
+    a.tc[0] = fetch_texcoord(in.p_texcoord[0], v, w);
+    a.tc[1] = fetch_texcoord(in.p_texcoord[1], v, w);
     vec3 pos = w.x * p0 + w.y * p1 + w.z * p2;
     vec3 ng = cross(p1 - p0, p2 - p0);                     // :196-199 un-normalised
     vec3 n, t;
     float tw;
-    if (in.tangent_space_descriptor != -1) {               // :201-222
-        const uint32_t* ts = (const uint32_t*)sc.buffers[in.tangent_space_descriptor].ptr;
+    if (has_ts) {                                          // :201-222
         vec3 n0, n1, n2, t0, t1, t2;
         float w0, w1, w2;
-        decode_tangent_space(ts[v[0]], n0, t0, w0);
-        decode_tangent_space(ts[v[1]], n1, t1, w1);
-        decode_tangent_space(ts[v[2]], n2, t2, w2);
+        decode_tangent_space(ts0, n0, t0, w0);
+        decode_tangent_space(ts1, n1, t1, w1);
+        decode_tangent_space(ts2, n2, t2, w2);
         n = w.x * n0 + w.y * n1 + w.z * n2;
         t = w.x * t0 + w.y * t1 + w.z * t2;
         tw = w0;                                           // winding from vertex 0 only (quirk q16)
@@ -199,15 +213,12 @@ PT_DEV HitGeom get_vertex_attributes(const SceneRec& sc, const pt_mesh_instance&
         t = normalize(cross(helper, ng));
         tw = 1;
     }
-    a.position = mul_point(in.transform, pos);
-    a.ng = normalize(mul_dir(in.normal_transform, ng));
-    a.n = normalize(mul_dir(in.normal_transform, n));
-    a.t = normalize(mul_dir(in.transform, t));
+    a.position = mul_point(in.gpu.transform, pos);
+    a.ng = normalize(mul_dir(in.gpu.normal_transform, ng));
+    a.n = normalize(mul_dir(in.gpu.normal_transform, n));
+    a.t = normalize(mul_dir(in.gpu.transform, t));
     a.tw = tw;
     a.bt = tw * normalize(cross(a.n, a.t));                // :224-227
-    a.color = fetch_vertex_color(sc, in.color_descriptor, v, w);
-    a.tc[0] = fetch_texcoord(sc, in.texcoord_descriptors[0], v, w);
-    a.tc[1] = fetch_texcoord(sc, in.texcoord_descriptors[1], v, w);
     return a;
 }
 
@@ -218,27 +229,50 @@ struct Surface {                       // live subset of SurfaceProperties (Bsdf
     vec3 spec_color; float spec_factor, clearcoat, cc_rough;
     vec3 cc_n, sheen_color; float sheen_a, transmissive;
 };
-PT_DEV vec4 base_color(const SceneRec& sc, const pt_material& m, const vec2 tc[2], vec4 vc, unsigned& taps) {   // Material.hlsli:98-106
-    vec4 c = {m.base_color_factor[0], m.base_color_factor[1], m.base_color_factor[2], m.base_color_factor[3]};
-    c = c * vc;
-    if (m.albedo.descriptor != -1) c = c * sample_material_texture(sc, m.albedo, tc, taps);
-    return c;
+struct MatHeader {                     // the 128-B head of RMat in registers (8 x dwordx4 issued together)
+    uint32_t flags; int32_t alpha_mode; float metalness_factor, roughness_factor;
+    vec4 base_color_factor;
+    vec3 emissive_factor; float alpha_cutoff;
+    float ior, normal_scale, specular_factor, clearcoat_normal_scale;
+    vec3 specular_color_factor; float clearcoat_factor;
+    float clearcoat_roughness_factor, anisotropy_strength, anisotropy_cos, anisotropy_sin;
+    vec3 sheen_color_factor; float sheen_roughness_factor;
+    float transmission_factor; uint32_t bound_mask;
+};
+PT_DEV MatHeader load_mat_header(const RMat* m) {
+    const float4* q = (const float4*)m;
+    const float4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5], g = q[6], h = q[7];
+    MatHeader r;
+    r.flags = __float_as_uint(a.x); r.alpha_mode = __float_as_int(a.y); r.metalness_factor = a.z; r.roughness_factor = a.w;
+    r.base_color_factor = {b.x, b.y, b.z, b.w};
+    r.emissive_factor = v3(c.x, c.y, c.z); r.alpha_cutoff = c.w;
+    r.ior = d.x; r.normal_scale = d.y; r.specular_factor = d.z; r.clearcoat_normal_scale = d.w;
+    r.specular_color_factor = v3(e.x, e.y, e.z); r.clearcoat_factor = e.w;
+    r.clearcoat_roughness_factor = f.x; r.anisotropy_strength = f.y; r.anisotropy_cos = f.z; r.anisotropy_sin = f.w;
+    r.sheen_color_factor = v3(g.x, g.y, g.z); r.sheen_roughness_factor = g.w;
+    r.transmission_factor = h.x; r.bound_mask = __float_as_uint(h.y);
+    return r;
 }
-PT_DEV float alpha_of(const pt_material& m, vec4 c) {                                                         // :108-117
-    if (m.alpha_mode == PT_ALPHA_MODE_BLEND) return c.w;
-    if (m.alpha_mode == PT_ALPHA_MODE_MASK) return c.w < m.alpha_cutoff ? 0.f : 1.f;
-    return 1;
+PT_DEV bool slot_bound(uint32_t mask, int slot) { return (mask >> slot) & 1u; }
+// GetBaseColor + GetAlpha for the any-hit paths (Material.hlsli:98-117); only the fields they need are loaded.
+PT_DEV void base_color_alpha(const SceneRec& sc, const RMat* m, const vec2 tc[2], vec4 vc, unsigned& taps, float& base_alpha, float& alpha, float& cutoff) {
+    const float4* q = (const float4*)m;
+    const float4 a = q[0], b = q[1], c = q[2], h = q[7];
+    vec4 col = vec4{b.x, b.y, b.z, b.w} * vc;
+    if (slot_bound(__float_as_uint(h.y), SLOT_ALBEDO)) col = col * sample_slot(sc, m, SLOT_ALBEDO, tc, taps);
+    const int alpha_mode = __float_as_int(a.y);
+    cutoff = c.w;
+    base_alpha = col.w;
+    alpha = alpha_mode == PT_ALPHA_MODE_BLEND ? col.w : (alpha_mode == PT_ALPHA_MODE_MASK ? (col.w < cutoff ? 0.f : 1.f) : 1.f);
 }
-PT_DEV vec3 normal_from_map(const SceneRec& sc, const pt_texture_sample& a, float scale, const vec2 tc[2], vec3 gn, vec3 t, vec3 b, unsigned& taps) {  // :119-128,199-208
-    if (a.descriptor == -1) return gn;
-    vec4 s = sample_material_texture(sc, a, tc, taps);
+PT_DEV vec3 normal_from_sample(vec4 s, float scale, vec3 gn, vec3 t, vec3 b) {                        // Material.hlsli:119-128,199-208
     vec3 nm = v3(s.x * 2.f - 1.f, s.y * 2.f - 1.f, s.z * 2.f - 1.f);
     nm.x *= scale; nm.y *= scale;
     return normalize(to_world(t, b, gn, nm));
 }
-PT_DEV vec3 emissive_of(const SceneRec& sc, const pt_material& m, const vec2 tc[2], unsigned& taps) {         // :151-159
-    vec3 e = v3p(m.emissive_factor);
-    if (m.emissive.descriptor != -1) e = e * xyz(sample_material_texture(sc, m.emissive, tc, taps));
+PT_DEV vec3 emissive_of(const SceneRec& sc, const RMat* m, const MatHeader& h, const vec2 tc[2], unsigned& taps) {   // :151-159
+    vec3 e = h.emissive_factor;
+    if (slot_bound(h.bound_mask, SLOT_EMISSIVE)) e = e * xyz(sample_slot(sc, m, SLOT_EMISSIVE, tc, taps));
     return e;
 }
 PT_DEV vec3 normal_adaptation(vec3 ng, vec3 ns, vec3 v) {          // PathTracer.lib.hlsl:306-316
@@ -247,40 +281,60 @@ PT_DEV vec3 normal_adaptation(vec3 ng, vec3 ns, vec3 v) {          // PathTracer
     if (rdng < 0) return normalize(v + normalize(r - rdng * ng));
     return ns;
 }
-PT_DEV Surface get_surface(const SceneRec& sc, uint32_t flags, const pt_material& m, const HitGeom& a, vec3 view, unsigned& taps) {
+PT_DEV Surface get_surface(const SceneRec& sc, uint32_t flags, const RMat* m, const MatHeader& h, const HitGeom& a, vec3 view, unsigned& taps) {
     Surface s;
-    vec4 bc = base_color(sc, m, a.tc, a.color, taps);
+    // The three usual PBR textures are fetched as ONE batch: their slot records are loaded together, their twelve texel
+    // gathers are issued together (unbound slots read a 1x1 white texel, so there is no branch to split the batch).
+    const RTex t_alb = load_rtex(&m->tex[SLOT_ALBEDO]), t_nrm = load_rtex(&m->tex[SLOT_NORMAL]), t_mr = load_rtex(&m->tex[SLOT_METALLIC_ROUGHNESS]);
+    const TexTaps k_alb = texture_taps(t_alb, a.tc), k_nrm = texture_taps(t_nrm, a.tc), k_mr = texture_taps(t_mr, a.tc);
+    const uint32_t a00 = *k_alb.p00, a10 = *k_alb.p10, a01 = *k_alb.p01, a11 = *k_alb.p11;
+    const uint32_t n00 = *k_nrm.p00, n10 = *k_nrm.p10, n01 = *k_nrm.p01, n11 = *k_nrm.p11;
+    const uint32_t m00 = *k_mr.p00, m10 = *k_mr.p10, m01 = *k_mr.p01, m11 = *k_mr.p11;
+    const bool b_alb = slot_bound(h.bound_mask, SLOT_ALBEDO), b_nrm = slot_bound(h.bound_mask, SLOT_NORMAL), b_mr = slot_bound(h.bound_mask, SLOT_METALLIC_ROUGHNESS);
+    taps += (b_alb ? 1u : 0u) + (b_nrm ? 1u : 0u) + (b_mr ? 1u : 0u);
+    vec4 bc = h.base_color_factor * a.color;                                                      // GetBaseColor, Material.hlsli:98-106
+    if (b_alb) bc = bc * resolve_taps(k_alb, a00, a10, a01, a11, sc.srgb_lut);
     s.albedo = xyz(bc);
-    s.alpha = alpha_of(m, bc);
-    s.n = normal_from_map(sc, m.normal, m.normal_scale, a.tc, a.n, a.t, a.bt, taps);
+    s.alpha = h.alpha_mode == PT_ALPHA_MODE_BLEND ? bc.w : (h.alpha_mode == PT_ALPHA_MODE_MASK ? (bc.w < h.alpha_cutoff ? 0.f : 1.f) : 1.f);   // :108-117
+    s.n = b_nrm ? normal_from_sample(resolve_taps(k_nrm, n00, n10, n01, n11, sc.srgb_lut), h.normal_scale, a.n, a.t, a.bt) : a.n;
     if (flags & PT_FLAG_SHADING_NORMAL_ADAPTATION) s.n = normal_adaptation(a.ng, s.n, view);
-    float metal = m.metalness_factor, rough = m.roughness_factor;                                 // Material.hlsli:130-140
-    if (m.metallic_roughness.descriptor != -1) { vec4 t = sample_material_texture(sc, m.metallic_roughness, a.tc, taps); metal *= t.z; rough *= t.y; }
+    float metal = h.metalness_factor, rough = h.roughness_factor;                                 // Material.hlsli:130-140
+    if (b_mr) { vec4 t = resolve_taps(k_mr, m00, m10, m01, m11, sc.srgb_lut); metal *= t.z; rough *= t.y; }
     s.metalness = metal;
     s.ay = hmax(rough * rough, kMinRoughness);
     // PathTracer.lib.hlsl:339,341: occlusion and the first emissive fetch are dead values; the fetches are
     // skipped here (no visible effect) but still counted so tap counters match the reference's traffic.
-    if (m.occlusion.descriptor != -1) taps++;
-    if (m.emissive.descriptor != -1) taps++;
-    s.ior = m.ior;
-    s.spec_factor = m.specular_factor;                                                            // :161-168
-    if (m.specular.descriptor != -1) s.spec_factor *= sample_material_texture(sc, m.specular, a.tc, taps).w;
-    s.spec_color = v3p(m.specular_color_factor);                                                   // :170-177
-    if (m.specular_color.descriptor != -1) s.spec_color = s.spec_color * xyz(sample_material_texture(sc, m.specular_color, a.tc, taps));
-    s.clearcoat = m.clearcoat_factor;                                                             // :179-186
-    if (m.clearcoat.descriptor != -1) s.clearcoat *= sample_material_texture(sc, m.clearcoat, a.tc, taps).x;
-    s.cc_rough = m.clearcoat_roughness_factor;                                                    // :188-195
-    if (m.clearcoat_roughness.descriptor != -1) s.cc_rough *= sample_material_texture(sc, m.clearcoat_roughness, a.tc, taps).y;
-    s.cc_n = normal_from_map(sc, m.clearcoat_normal, m.clearcoat_normal_scale, a.tc, a.n, a.t, a.bt, taps);
-    if (flags & PT_FLAG_SHADING_NORMAL_ADAPTATION) s.cc_n = normal_adaptation(a.ng, s.cc_n, view);
-    // GetAnisotropyStrengthAndDirection (Material.hlsli:246-262)
-    float strength = m.anisotropy_strength;
+    if (slot_bound(h.bound_mask, SLOT_OCCLUSION)) taps++;
+    if (slot_bound(h.bound_mask, SLOT_EMISSIVE)) taps++;
+    s.ior = h.ior;
+    s.spec_factor = h.specular_factor;                                                            // :161-168
+    s.spec_color = h.specular_color_factor;                                                       // :170-177
+    s.clearcoat = h.clearcoat_factor;                                                             // :179-186
+    s.cc_rough = h.clearcoat_roughness_factor;                                                    // :188-195
+    s.cc_n = a.n;
+    float strength = h.anisotropy_strength;
     vec3 av = v3(1, 0, 1);
-    if (m.anisotropy.descriptor != -1) {
-        vec4 t = sample_material_texture(sc, m.anisotropy, a.tc, taps);
-        av = v3(t.x * 2 - 1, t.y * 2 - 1, t.z);
+    s.sheen_color = h.sheen_color_factor;                                                         // :210-217
+    float sheen_rough = h.sheen_roughness_factor;                                                 // :219-226
+    s.transmissive = h.transmission_factor;                                                       // :228-235
+    if (h.bound_mask >> SLOT_SPECULAR) {                   // any of the rarely-bound extension textures (slots 5..14)
+        if (slot_bound(h.bound_mask, SLOT_SPECULAR)) s.spec_factor *= sample_slot(sc, m, SLOT_SPECULAR, a.tc, taps).w;
+        if (slot_bound(h.bound_mask, SLOT_SPECULAR_COLOR)) s.spec_color = s.spec_color * xyz(sample_slot(sc, m, SLOT_SPECULAR_COLOR, a.tc, taps));
+        if (slot_bound(h.bound_mask, SLOT_CLEARCOAT)) s.clearcoat *= sample_slot(sc, m, SLOT_CLEARCOAT, a.tc, taps).x;
+        if (slot_bound(h.bound_mask, SLOT_CLEARCOAT_ROUGHNESS)) s.cc_rough *= sample_slot(sc, m, SLOT_CLEARCOAT_ROUGHNESS, a.tc, taps).y;
+        if (slot_bound(h.bound_mask, SLOT_CLEARCOAT_NORMAL))
+            s.cc_n = normal_from_sample(sample_slot(sc, m, SLOT_CLEARCOAT_NORMAL, a.tc, taps), h.clearcoat_normal_scale, a.n, a.t, a.bt);
+        if (slot_bound(h.bound_mask, SLOT_ANISOTROPY)) {   // GetAnisotropyStrengthAndDirection (Material.hlsli:246-262)
+            vec4 t = sample_slot(sc, m, SLOT_ANISOTROPY, a.tc, taps);
+            av = v3(t.x * 2 - 1, t.y * 2 - 1, t.z);
+        }
+        if (slot_bound(h.bound_mask, SLOT_SHEEN_COLOR)) s.sheen_color = s.sheen_color * xyz(sample_slot(sc, m, SLOT_SHEEN_COLOR, a.tc, taps));
+        if (slot_bound(h.bound_mask, SLOT_SHEEN_ROUGHNESS)) sheen_rough *= sample_slot(sc, m, SLOT_SHEEN_ROUGHNESS, a.tc, taps).w;
+        if (slot_bound(h.bound_mask, SLOT_TRANSMISSION)) s.transmissive *= sample_slot(sc, m, SLOT_TRANSMISSION, a.tc, taps).x;
+        if (slot_bound(h.bound_mask, SLOT_THICKNESS)) taps++;   // thickness is loaded upstream but unused (quirk q14)
     }
-    float cr = cosf(m.anisotropy_rotation), sr = sinf(m.anisotropy_rotation);
+    if (flags & PT_FLAG_SHADING_NORMAL_ADAPTATION) s.cc_n = normal_adaptation(a.ng, s.cc_n, view);
+    const float cr = h.anisotropy_cos, sr = h.anisotropy_sin;
     vec2 adir = normalize(vec2{cr * av.x + -sr * av.y, sr * av.x + cr * av.y});
     strength *= av.z;
     // CalculateShadingTangentAndBitangent (Material.hlsli:264-270)
@@ -290,14 +344,7 @@ PT_DEV Surface get_surface(const SceneRec& sc, uint32_t flags, const pt_material
     s.at = normalize(to_world(st, sb, s.n, v3(adir.x, adir.y, 0)));
     s.ab = normalize(cross(s.at, s.n));
     s.ax = hmax(lerpf(s.ay, 1, strength * strength), kMinRoughness);
-    s.sheen_color = v3p(m.sheen_color_factor);                                                     // :210-217
-    if (m.sheen_color.descriptor != -1) s.sheen_color = s.sheen_color * xyz(sample_material_texture(sc, m.sheen_color, a.tc, taps));
-    float sheen_rough = m.sheen_roughness_factor;                                                 // :219-226
-    if (m.sheen_roughness.descriptor != -1) sheen_rough *= sample_material_texture(sc, m.sheen_roughness, a.tc, taps).w;
     s.sheen_a = hmax(sheen_rough * sheen_rough, kMinRoughness);
-    s.transmissive = m.transmission_factor;                                                       // :228-235
-    if (m.transmission.descriptor != -1) s.transmissive *= sample_material_texture(sc, m.transmission, a.tc, taps).x;
-    if (m.thickness.descriptor != -1) taps++;            // thickness is loaded upstream but unused (quirk q14)
     // ClosestHit :856-861
     s.ax = hmax(s.ax, kMinRoughness); s.ay = hmax(s.ay, kMinRoughness);
     s.cc_rough = hmax(s.cc_rough, kMinRoughness);

@@ -38,17 +38,13 @@ struct LaneStats { unsigned nodes, tris, taps, overflow; };
 // Alpha of a candidate hit: AnyHit / ShadowAnyHit (PathTracer.lib.hlsl:1010-1035, 1053-1079).
 PT_DEV void candidate_alpha(const SceneRec& sc, uint32_t inst, uint32_t prim, float u, float v, unsigned& taps, float& base_alpha,
                             float& alpha, float& cutoff) {
-    const pt_mesh_instance& in = sc.instances[inst].gpu;
-    const pt_material& m = sc.materials[in.material_id];
+    const InstanceRec& in = sc.instances[inst];
     vec3 w = v3(1 - u - v, u, v);
     uint32_t vi[3];
-    fetch_indices(sc, in.index_descriptor, prim, vi);
-    vec4 c = fetch_vertex_color(sc, in.color_descriptor, vi, w);
-    vec2 tc[2] = {fetch_texcoord(sc, in.texcoord_descriptors[0], vi, w), fetch_texcoord(sc, in.texcoord_descriptors[1], vi, w)};
-    c = base_color(sc, m, tc, c, taps);
-    base_alpha = c.w;
-    alpha = alpha_of(m, c);
-    cutoff = m.alpha_cutoff;
+    fetch_indices(in, prim, vi);
+    vec4 c = fetch_vertex_color(in, vi, w);
+    vec2 tc[2] = {fetch_texcoord(in.p_texcoord[0], vi, w), fetch_texcoord(in.p_texcoord[1], vi, w)};
+    base_color_alpha(sc, sc.rmats + in.gpu.material_id, tc, c, taps, base_alpha, alpha, cutoff);
 }
 
 // Per-lane traversal state.

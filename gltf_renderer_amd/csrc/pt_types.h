@@ -23,15 +23,52 @@ struct TextureRec {         // RGBA8, one mip (Gltf.cpp:1059-1060)
 };
 struct SamplerRec { int32_t address_u, address_v, min_filter, mag_filter; };
 
-// Instance table row: Instance (PathTracer.lib.hlsl:32-41) + what the TLAS instance desc carried.
-struct InstanceRec {
+// Instance table row: Instance (PathTracer.lib.hlsl:32-41) + what the TLAS instance desc carried + the stream
+// pointers its descriptors resolve to (one dependent load fewer per vertex fetch than going through the table).
+struct __attribute__((aligned(16))) InstanceRec {
     pt_mesh_instance gpu;   // 156 B
     uint32_t mask_flags;    // bits 0-7 instance mask, bit 8 cull-disable, bit 9 force-non-opaque, bit 10 mirrored
     uint32_t tri_offset;    // first triangle of this instance in build order
     uint32_t tri_count;
-    uint32_t _pad[2];
+    uint32_t index_is16;    // index stream format (R16_UINT vs R32_UINT)
+    uint32_t _pad;
+    const void* p_index;            // nullptr = non-indexed
+    const float* p_position;
+    const uint32_t* p_tangent_space;   // nullptr = absent
+    const float2* p_texcoord[2];
+    const uint2* p_color;
+    uint64_t _pad2;
 };
-static_assert(sizeof(InstanceRec) == 176, "InstanceRec");
+static_assert(sizeof(InstanceRec) == 240, "InstanceRec");
+
+// Resolved material: what the kernels read instead of pt_material + texture/sampler tables.  Built on the host by
+// pt_scene_set_materials; laid out so the header is 8 dwordx4 loads issued together and a texture slot is 3.
+// The UV transform rows (T*(R*S), Material.hlsli:68-88) are pre-multiplied in fp32 exactly as the shader would.
+struct __attribute__((aligned(16))) RTex {
+    const uint32_t* texels;        // unbound slots point at a 1x1 white texel, so address math needs no branch
+    int32_t width, height;
+    uint32_t flags;                // bit 0 sRGB, bits 1-2 address_u, bits 3-4 address_v, bit 5 point filter, bit 6 tex_coord set
+    float m00, m01, ox;            // tu = m00*u + m01*v + ox
+    float m10, m11, oy;            // tv = m10*u + m11*v + oy
+    uint32_t _pad;
+};
+static_assert(sizeof(RTex) == 48, "RTex");
+enum { RT_SRGB = 1, RT_POINT = 32, RT_TEXCOORD1 = 64 };
+enum { SLOT_NORMAL = 0, SLOT_ALBEDO, SLOT_METALLIC_ROUGHNESS, SLOT_OCCLUSION, SLOT_EMISSIVE, SLOT_SPECULAR, SLOT_SPECULAR_COLOR, SLOT_CLEARCOAT,
+       SLOT_CLEARCOAT_ROUGHNESS, SLOT_CLEARCOAT_NORMAL, SLOT_ANISOTROPY, SLOT_SHEEN_COLOR, SLOT_SHEEN_ROUGHNESS, SLOT_TRANSMISSION, SLOT_THICKNESS,
+       SLOT_COUNT };
+struct __attribute__((aligned(16))) RMat {
+    uint32_t flags; int32_t alpha_mode; float metalness_factor, roughness_factor;
+    float base_color_factor[4];
+    float emissive_factor[3], alpha_cutoff;
+    float ior, normal_scale, specular_factor, clearcoat_normal_scale;
+    float specular_color_factor[3], clearcoat_factor;
+    float clearcoat_roughness_factor, anisotropy_strength, anisotropy_cos, anisotropy_sin;   // cos/sin(anisotropy_rotation), fp32
+    float sheen_color_factor[3], sheen_roughness_factor;
+    float transmission_factor; uint32_t bound_mask; uint32_t _pad[2];                        // bit k: slot k has a texture
+    RTex tex[SLOT_COUNT];
+};
+static_assert(sizeof(RMat) == 128 + 48 * 15, "RMat");
 
 // 64-B BVH2 node: both children's boxes + child references (>=0 inner node, <0 leaf: ~triangle index).
 struct __attribute__((aligned(64))) BvhNode {
@@ -72,10 +109,7 @@ struct EnvRec {
 };
 
 struct SceneRec {
-    const BufferRec* buffers;
-    const TextureRec* textures;
-    const SamplerRec* samplers;
-    const pt_material* materials;
+    const RMat* rmats;          // resolved materials (index = material_id)
     const pt_light* lights;
     const InstanceRec* instances;
     const Bvh4Node* nodes;

@@ -49,9 +49,10 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
     fu.q_env = fu.q_light = fu.q_bounce = false;
     const float4* tp = (const float4*)sc.tris + (size_t)hit.tri * 3;
     const uint32_t inst_id = __float_as_uint(tp[0].w), prim = __float_as_uint(tp[1].w);
-    const pt_mesh_instance& inst = sc.instances[inst_id].gpu;
-    const pt_material& mat = sc.materials[inst.material_id];
-    HitGeom va = get_vertex_attributes(sc, inst, prim, v3(1 - hit.u - hit.v, hit.u, hit.v));
+    const InstanceRec& inst = sc.instances[inst_id];
+    const RMat* mat = sc.rmats + inst.gpu.material_id;
+    const MatHeader mh = load_mat_header(mat);             // issued before the vertex gathers so both are in flight together
+    HitGeom va = get_vertex_attributes(inst, prim, v3(1 - hit.u - hit.v, hit.u, hit.v));
     const int dbg = fc.debug_output;
     if (dbg >= PT_DEBUG_OUTPUT_HIT_KIND && dbg <= PT_DEBUG_OUTPUT_TEXCOORD_1) {                       // :806-840
         vec3 c;
@@ -72,7 +73,7 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
     const vec3 intersection = ray.o + (ray.d * hit.t);                                               // :849
     const vec3 o_above = offset_ray(va.position, va.ng), o_below = offset_ray(va.position, -va.ng);
     const vec3 view = -normalize(ray.d);
-    Surface sp = get_surface(sc, flags, mat, va, view, taps);
+    Surface sp = get_surface(sc, flags, mat, mh, va, view, taps);
     if (dbg >= PT_DEBUG_OUTPUT_COLOR && dbg <= PT_DEBUG_OUTPUT_TRANSMISSIVE) {                       // :863-917
         vec3 c;
         switch (dbg) {
@@ -98,7 +99,7 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
         return true;
     }
     const Lobes lobes = lobe_probabilities(sp, view);
-    vec3 c = emissive_of(sc, mat, va.tc, taps);                                                      // :925-926
+    vec3 c = emissive_of(sc, mat, mh, va.tc, taps);                                                     // :925-926
     fu.origin_above = o_above;
     // environment NEE :929-942 (SampleEnvironmentMap :688-703)
     if (ps.bounce < fc.max_bounces && (flags & PT_FLAG_ENVIRONMENT_MAP) && (flags & PT_FLAG_ENVIRONMENT_MIS)) {
