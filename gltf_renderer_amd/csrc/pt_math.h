@@ -17,6 +17,18 @@ struct vec2 { float x, y; };
 struct vec3 { float x, y, z; };
 struct vec4 { float x, y, z, w; };
 
+// Loads through a pointer that was itself read from memory (stream pointers in instance rows, texel pointers in material
+// slots) would compile to flat_load, which ties up both the vector-memory and the LDS wait counters.  Everything the kernels
+// gather lives in HBM, so say so: these compile to global_load.
+#define PT_GLOBAL __attribute__((address_space(1)))
+typedef float pt_f4n __attribute__((ext_vector_type(4)));
+typedef float pt_f2n __attribute__((ext_vector_type(2)));
+typedef uint32_t pt_u2n __attribute__((ext_vector_type(2)));
+template <class T> PT_DEV T gload(const T* p) { return *(const PT_GLOBAL T*)p; }                     // scalar types only
+PT_DEV float4 gload_f4(const void* p) { pt_f4n v = *(const PT_GLOBAL pt_f4n*)p; return make_float4(v.x, v.y, v.z, v.w); }
+PT_DEV float2 gload_f2(const void* p) { pt_f2n v = *(const PT_GLOBAL pt_f2n*)p; return make_float2(v.x, v.y); }
+PT_DEV uint2 gload_u2(const void* p) { pt_u2n v = *(const PT_GLOBAL pt_u2n*)p; return make_uint2(v.x, v.y); }
+
 PT_DEV vec3 v3(float a) { return {a, a, a}; }
 PT_DEV vec3 v3(float x, float y, float z) { return {x, y, z}; }
 PT_DEV vec3 v3p(const float* p) { return {p[0], p[1], p[2]}; }

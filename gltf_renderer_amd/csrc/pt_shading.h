@@ -89,9 +89,19 @@ PT_DEV int wrap_addr(int i, int n, int mode) {
     }
     return i < 0 ? 0 : (i >= n ? n - 1 : i);
 }
+// The sRGB decode table is gathered with lane-random indices 12+ times per hit.  Kernels built with PT_LUT_LDS stage it into
+// LDS once per workgroup (stage_luts), where a random 4-byte gather costs a few cycles instead of one L1 line per distinct index.
+#ifdef PT_LUT_LDS
+static __shared__ float pt_lds_srgb[256];
+PT_DEV void stage_luts(const SceneRec& sc) { pt_lds_srgb[threadIdx.x & 255u] = sc.srgb_lut[threadIdx.x & 255u]; __syncthreads(); }
+PT_DEV float srgb_decode(const float*, uint32_t i) { return pt_lds_srgb[i]; }
+#else
+PT_DEV void stage_luts(const SceneRec&) {}
+PT_DEV float srgb_decode(const float* lut, uint32_t i) { return lut[i]; }
+#endif
 PT_DEV vec4 unpack_texel(uint32_t t, uint32_t srgb, const float* lut) {
     uint32_t r = t & 0xff, g = (t >> 8) & 0xff, b = (t >> 16) & 0xff, a = t >> 24;
-    if (srgb) return {lut[r], lut[g], lut[b], (float)a / 255.0f};
+    if (srgb) return {srgb_decode(lut, r), srgb_decode(lut, g), srgb_decode(lut, b), (float)a / 255.0f};
     return {(float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f, (float)a / 255.0f};
 }
 PT_DEV float finite_coord(float x) {
@@ -146,7 +156,7 @@ PT_DEV vec4 sample_slot(const SceneRec& sc, const RMat* m, int slot, const vec2 
     const RTex t = load_rtex(&m->tex[slot]);
     const TexTaps k = texture_taps(t, tc);
     taps++;
-    return resolve_taps(k, *k.p00, *k.p10, *k.p01, *k.p11, sc.srgb_lut);
+    return resolve_taps(k, gload(k.p00), gload(k.p10), gload(k.p01), gload(k.p11), sc.srgb_lut);
 }
 
 // ---------------------------------------------------------------- vertex fetch (PathTracer.lib.hlsl:176-302)
@@ -155,22 +165,22 @@ PT_DEV void fetch_indices(const InstanceRec& in, uint32_t prim, uint32_t v[3]) {
     if (in.p_index) {
         if (in.index_is16) {
             const uint16_t* p = (const uint16_t*)in.p_index;
-            v[0] = p[v[0]]; v[1] = p[v[1]]; v[2] = p[v[2]];
+            v[0] = gload(p + v[0]); v[1] = gload(p + v[1]); v[2] = gload(p + v[2]);
         } else {
             const uint32_t* p = (const uint32_t*)in.p_index;
-            v[0] = p[v[0]]; v[1] = p[v[1]]; v[2] = p[v[2]];
+            v[0] = gload(p + v[0]); v[1] = gload(p + v[1]); v[2] = gload(p + v[2]);
         }
     }
 }
 PT_DEV vec4 fetch_vertex_color(const InstanceRec& in, const uint32_t v[3], vec3 w) {                 // :229-242
     if (!in.p_color) return {1, 1, 1, 1};
-    const uint2 q0 = in.p_color[v[0]], q1 = in.p_color[v[1]], q2 = in.p_color[v[2]];
+    const uint2 q0 = gload_u2(in.p_color + v[0]), q1 = gload_u2(in.p_color + v[1]), q2 = gload_u2(in.p_color + v[2]);
     auto un = [](uint2 q) { return vec4{(float)(q.x & 0xffff) / 65535.f, (float)(q.x >> 16) / 65535.f, (float)(q.y & 0xffff) / 65535.f, (float)(q.y >> 16) / 65535.f}; };
     return un(q0) * w.x + un(q1) * w.y + un(q2) * w.z;
 }
 PT_DEV vec2 fetch_texcoord(const float2* p, const uint32_t v[3], vec3 w) {                           // :244-257
     if (!p) return {0, 0};
-    float2 a = p[v[0]], b = p[v[1]], c = p[v[2]];
+    float2 a = gload_f2(p + v[0]), b = gload_f2(p + v[1]), c = gload_f2(p + v[2]);
     return {w.x * a.x + w.y * b.x + w.z * c.x, w.x * a.y + w.y * b.y + w.z * c.y};
 }
 struct HitGeom {                       // VertexAttributes, PathTracer.lib.hlsl:270-278
@@ -186,10 +196,10 @@ PT_DEV HitGeom get_vertex_attributes(const InstanceRec& in, uint32_t prim, vec3 
     // issue every stream's gathers before using any of them (one memory round trip for all attributes)
     const float* pp = in.p_position;
     const float *q0 = pp + (size_t)v[0] * 3, *q1 = pp + (size_t)v[1] * 3, *q2 = pp + (size_t)v[2] * 3;
-    vec3 p0 = v3(q0[0], q0[1], q0[2]), p1 = v3(q1[0], q1[1], q1[2]), p2 = v3(q2[0], q2[1], q2[2]);
+    vec3 p0 = v3(gload(q0), gload(q0 + 1), gload(q0 + 2)), p1 = v3(gload(q1), gload(q1 + 1), gload(q1 + 2)), p2 = v3(gload(q2), gload(q2 + 1), gload(q2 + 2));
     uint32_t ts0 = 0, ts1 = 0, ts2 = 0;
     const bool has_ts = in.p_tangent_space != nullptr;
-    if (has_ts) { ts0 = in.p_tangent_space[v[0]]; ts1 = in.p_tangent_space[v[1]]; ts2 = in.p_tangent_space[v[2]]; }
+    if (has_ts) { ts0 = gload(in.p_tangent_space + v[0]); ts1 = gload(in.p_tangent_space + v[1]); ts2 = gload(in.p_tangent_space + v[2]); }
     a.color = fetch_vertex_color(in, v, w);
     a.tc[0] = fetch_texcoord(in.p_texcoord[0], v, w);
     a.tc[1] = fetch_texcoord(in.p_texcoord[1], v, w);
@@ -287,9 +297,9 @@ PT_DEV Surface get_surface(const SceneRec& sc, uint32_t flags, const RMat* m, co
     // gathers are issued together (unbound slots read a 1x1 white texel, so there is no branch to split the batch).
     const RTex t_alb = load_rtex(&m->tex[SLOT_ALBEDO]), t_nrm = load_rtex(&m->tex[SLOT_NORMAL]), t_mr = load_rtex(&m->tex[SLOT_METALLIC_ROUGHNESS]);
     const TexTaps k_alb = texture_taps(t_alb, a.tc), k_nrm = texture_taps(t_nrm, a.tc), k_mr = texture_taps(t_mr, a.tc);
-    const uint32_t a00 = *k_alb.p00, a10 = *k_alb.p10, a01 = *k_alb.p01, a11 = *k_alb.p11;
-    const uint32_t n00 = *k_nrm.p00, n10 = *k_nrm.p10, n01 = *k_nrm.p01, n11 = *k_nrm.p11;
-    const uint32_t m00 = *k_mr.p00, m10 = *k_mr.p10, m01 = *k_mr.p01, m11 = *k_mr.p11;
+    const uint32_t a00 = gload(k_alb.p00), a10 = gload(k_alb.p10), a01 = gload(k_alb.p01), a11 = gload(k_alb.p11);
+    const uint32_t n00 = gload(k_nrm.p00), n10 = gload(k_nrm.p10), n01 = gload(k_nrm.p01), n11 = gload(k_nrm.p11);
+    const uint32_t m00 = gload(k_mr.p00), m10 = gload(k_mr.p10), m01 = gload(k_mr.p01), m11 = gload(k_mr.p11);
     const bool b_alb = slot_bound(h.bound_mask, SLOT_ALBEDO), b_nrm = slot_bound(h.bound_mask, SLOT_NORMAL), b_mr = slot_bound(h.bound_mask, SLOT_METALLIC_ROUGHNESS);
     taps += (b_alb ? 1u : 0u) + (b_nrm ? 1u : 0u) + (b_mr ? 1u : 0u);
     vec4 bc = h.base_color_factor * a.color;                                                      // GetBaseColor, Material.hlsli:98-106

@@ -82,7 +82,11 @@ PT_DEV void trav_push(Trav& t, int* lds_stack, int* spill, int ref, LaneStats& s
 PT_DEV void trav_pop(Trav& t, const int* lds_stack, const int* spill) {
     if (t.sp == 0) { t.cur = kTravDone; return; }
     t.sp--;
-    t.cur = t.sp < kStackLds ? lds_stack[t.sp * kBlock] : spill[t.sp - kStackLds];
+    // always a ds_read (a select between the LDS and the scratch address would make this a flat_load on every pop)
+    int v = lds_stack[min(t.sp, kStackLds - 1) * kBlock];
+    asm volatile("" : "+v"(v));                            // keep the two loads apart (the optimiser would re-merge them)
+    if (t.sp >= kStackLds) v = spill[t.sp - kStackLds];
+    t.cur = v;
 }
 
 #define PT_CSWAP(a, b) { uint32_t _lo = min(a, b), _hi = max(a, b); a = _lo; b = _hi; }

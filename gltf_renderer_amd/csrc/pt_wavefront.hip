@@ -17,6 +17,7 @@
 // Determinism: a pixel's radiance is accumulated in its own slot in a fixed order (hit terms, then the
 // env-shadow term, then the light-shadow term of that vertex), independent of queue order, so frames are
 // bit-reproducible and N tile shards compose bit-exactly.
+#define PT_LUT_LDS 1          // every stage kernel of this file stages the sRGB table into LDS (pt_shading.h stage_luts)
 #include "pt_vertex.h"
 #include "pt_host.h"
 
@@ -189,6 +190,7 @@ PT_DEV void trace_persistent(const SceneRec& sc, const WfBuffers& wf, int* my_st
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_trace(SceneRec sc, WfBuffers wf, int cur, uint32_t rf, uint32_t rmask, Counters* __restrict__ counters) {
     __shared__ int s_stack[kStackLds * kBlock];
+    stage_luts(sc);
     const ShardView sv = shard_view(wf);
     // member 0 of each shard zeroes the counters the following shade stage fills
     if (sv.member == 0 && threadIdx.x == 0) { wf.cnt[cur ^ 1][sv.shard * kCounterStride] = 0; wf.cnt[2][sv.shard * kCounterStride] = 0; }
@@ -210,6 +212,7 @@ PT_DEV void apply_pending(const WfBuffers& wf, uint32_t slot, vec3& L) {
 #define PT_SHADE_WAVES 2      // waves per SIMD the register allocator must leave room for (2 -> <= 256 VGPR+AGPR)
 #endif
 __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc, FrameConstants fc, WfBuffers wf, int cur, Counters* __restrict__ counters) {
+    stage_luts(sc);
     const ShardView sv = shard_view(wf);
     const uint32_t n = wf.cnt[cur][sv.shard * kCounterStride];
     const int nxt = cur ^ 1;
@@ -294,6 +297,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_shadow(SceneRec sc, WfBuffers wf, uint32_t flags, Counters* __restrict__ counters) {
     __shared__ int s_stack[kStackLds * kBlock];
+    stage_luts(sc);
     const ShardView sv = shard_view(wf);
     LaneStats st = {0, 0, 0, 0};
     trace_persistent<COUNT, 1>(sc, wf, s_stack + threadIdx.x, sv, 0, 0, 0xff, flags, st);
