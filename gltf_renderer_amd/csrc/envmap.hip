@@ -78,6 +78,13 @@ __global__ __launch_bounds__(256) void k_importance_level(const float* __restric
     out[(size_t)y * n + x] = sum;
 }
 
+// 4x4-blocked copy of one pyramid level: texel (x, y) -> block (x/4, y/4), position (y%4)*4 + x%4 inside it.
+__global__ __launch_bounds__(256) void k_importance_block(const float* __restrict__ in, float* __restrict__ out, int n) {
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= n) return;
+    out[((size_t)(y >> 2) * (n >> 2) + (x >> 2)) * 16 + (y & 3) * 4 + (x & 3)] = in[(size_t)y * n + x];
+}
+
 hipError_t env_build(EnvDevice& e, const float* d_equirect, int w, int h, hipStream_t stream) {
     int N = (w / 4) / 2;
     N = (N > 1 ? N : 1) + 1;                                     // EnvironmentMap.cpp:92 (quirk q11)
@@ -112,12 +119,23 @@ hipError_t env_build(EnvDevice& e, const float* d_equirect, int w, int h, hipStr
         hipLaunchKernelGGL(k_importance_level, dim3((n + 255) / 256, n), dim3(256), 0, stream, e.importance + e.level_offset[l - 1],
                            e.importance + e.level_offset[l], n);
     }
+    // blocked copies for the two-levels-per-fetch sampling descent (pt_shading.h sample_importance_map)
+    static_assert(sizeof(e.blocked_offset) / sizeof(e.blocked_offset[0]) == 5, "five level pairs");
+    if (e.imp_res != 1024 || e.levels != 11) return hipErrorInvalidValue;       // IMPORTANCE_MAP_SIZE is a constant of the reference
+    uint32_t bo = 0;
+    for (int k = 0; k < 5; k++) { int n = 4 << (2 * k); e.blocked_offset[k] = bo; bo += (uint32_t)n * n; }
+    if ((err = hipMalloc(&e.blocked, (size_t)bo * 4))) return err;
+    for (int k = 0; k < 5; k++) {
+        int n = 4 << (2 * k), l = 8 - 2 * k;                     // level l has resolution 1024 >> l
+        hipLaunchKernelGGL(k_importance_block, dim3((n + 255) / 256, n), dim3(256), 0, stream, e.importance + e.level_offset[l],
+                           e.blocked + e.blocked_offset[k], n);
+    }
     return hipGetLastError();
 }
 
 void env_free(EnvDevice& e) {
-    hipFree(e.cube); hipFree(e.importance);
-    e.cube = nullptr; e.importance = nullptr;
+    hipFree(e.cube); hipFree(e.importance); hipFree(e.blocked);
+    e.cube = nullptr; e.importance = nullptr; e.blocked = nullptr;
 }
 
 }  // namespace pt

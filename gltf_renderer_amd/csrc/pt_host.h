@@ -39,6 +39,8 @@ struct EnvDevice {
     uint32_t level_offset[12] = {0};
     int levels = 0;
     int imp_res = 1024;
+    float* blocked = nullptr;          // 4x4-blocked copies of levels 4^2, 16^2, 64^2, 256^2, 1024^2 (EnvRec::blocked)
+    uint32_t blocked_offset[5] = {0};
 };
 hipError_t env_build(EnvDevice& e, const float* d_equirect, int w, int h, hipStream_t stream);
 void env_free(EnvDevice& e);

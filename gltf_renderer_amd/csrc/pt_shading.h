@@ -702,32 +702,43 @@ PT_DEV float imp_load(const EnvRec& e, int level, uint32_t x, uint32_t y) {
     if (x >= n || y >= n) return 0.f;
     return e.importance[e.level_offset[level] + (size_t)y * n + x];
 }
-PT_DEV vec2 sample_importance_map(const EnvRec& e, float ux, float uy, float& pdf) {                          // Sampling.hlsli:123-163
+// One level of SampleImportanceMap (Sampling.hlsli:131-158): pick left/right by the column sums, then upper/lower inside the
+// chosen column, re-normalising the random numbers.  sx/sy = 1 for right / lower.
+PT_DEV void importance_step(float ul, float ur, float ll, float lr, float& ux, float& uy, uint32_t& sx, uint32_t& sy) {
+    const float left = ul + ll, right = ur + lr, total = left + right;
+    const float prob_left = left / total;
+    const bool go_left = ux < prob_left;
+    ux = (go_left ? ux : ux - prob_left) / (go_left ? prob_left : 1 - prob_left);
+    const float prob_upper = (go_left ? ul : ur) / (go_left ? left : right);
+    const bool up = uy < prob_upper;
+    uy = (up ? uy : uy - prob_upper) / (up ? prob_upper : 1 - prob_upper);
+    sx = go_left ? 0u : 1u;
+    sy = up ? 0u : 1u;
+}
+PT_DEV vec2 sample_importance_map(const EnvRec& e, float ux, float uy, float& pdf) {                         // Sampling.hlsli:123-163
+    // The reference descends ten levels with four dependent point loads each.  Here one 64-B fetch of a 4x4 block of the
+    // finer level of a pair serves two levels: the coarser level's 2x2 values are re-summed from the block in the order the
+    // pyramid build uses (k_importance_level: ((ul + ll) + ur) + lr), which reproduces the stored sums bit for bit.
     uint32_t px = 0, py = 0;
-    for (int i = e.imp_levels - 2; i >= 0; i--) {
-        px <<= 1; py <<= 1;
-        uint32_t n = (uint32_t)e.imp_res >> i;
-        const float* lv = e.importance + e.level_offset[i];
-        float2 top = *(const float2*)(lv + (size_t)py * n + px);          // px is even: 8-B aligned pair
-        float2 bot = *(const float2*)(lv + (size_t)(py + 1) * n + px);
-        float ul = top.x, ur = top.y, ll = bot.x, lr = bot.y;
-        float left = ul + ll, right = ur + lr, total = left + right;
-        float prob_left = left / total;
-        if (ux < prob_left) {
-            ux /= prob_left;
-            float prob_upper = ul / left;
-            if (uy < prob_upper) uy /= prob_upper;
-            else { py++; uy = (uy - prob_upper) / (1 - prob_upper); }
-        } else {
-            px++;
-            ux = (ux - prob_left) / (1 - prob_left);
-            float prob_upper = ur / right;
-            if (uy < prob_upper) uy /= prob_upper;
-            else { py++; uy = (uy - prob_upper) / (1 - prob_upper); }
-        }
+    float value = 0.f;
+#pragma unroll 1
+    for (int k = 0; k < 5; k++) {
+        const uint32_t nb = 1u << (2 * k);                                 // blocks per row of this pair's finer level
+        const float4* blk = (const float4*)(e.blocked + e.blocked_offset[k]) + ((size_t)py * nb + px) * 4;
+        const float4 r0 = blk[0], r1 = blk[1], r2 = blk[2], r3 = blk[3];
+        const float a_ul = ((r0.x + r1.x) + r0.y) + r1.y, a_ur = ((r0.z + r1.z) + r0.w) + r1.w;
+        const float a_ll = ((r2.x + r3.x) + r2.y) + r3.y, a_lr = ((r2.z + r3.z) + r2.w) + r3.w;
+        uint32_t sx, sy, tx, ty;
+        importance_step(a_ul, a_ur, a_ll, a_lr, ux, uy, sx, sy);
+        const float4 top = sy ? r2 : r0, bot = sy ? r3 : r1;              // the chosen texel's 2x2 children
+        const float ul = sx ? top.z : top.x, ur = sx ? top.w : top.y, ll = sx ? bot.z : bot.x, lr = sx ? bot.w : bot.y;
+        importance_step(ul, ur, ll, lr, ux, uy, tx, ty);
+        value = ty ? (tx ? lr : ll) : (tx ? ur : ul);
+        px = (px << 2) | (sx << 1) | tx;
+        py = (py << 2) | (sy << 1) | ty;
     }
     float w = (float)e.imp_res;
-    pdf = w * w * imp_load(e, 0, px, py) / imp_load(e, e.imp_levels - 1, 0, 0);
+    pdf = w * w * value / imp_load(e, e.imp_levels - 1, 0, 0);      // value = level-0 texel (px, py)
     return {((float)px + ux) / w, ((float)py + uy) / w};      // both axes / width (quirk q10)
 }
 PT_DEV float importance_map_pdf(const EnvRec& e, vec2 uv) {                                                   // Sampling.hlsli:165-174, Common.hlsli:12-15
