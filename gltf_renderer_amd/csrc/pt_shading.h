@@ -92,12 +92,18 @@ PT_DEV int wrap_addr(int i, int n, int mode) {
 // The sRGB decode table is gathered with lane-random indices 12+ times per hit.  Kernels built with PT_LUT_LDS stage it into
 // LDS once per workgroup (stage_luts), where a random 4-byte gather costs a few cycles instead of one L1 line per distinct index.
 #ifdef PT_LUT_LDS
-static __shared__ float pt_lds_srgb[256];
-PT_DEV void stage_luts(const SceneRec& sc) { pt_lds_srgb[threadIdx.x & 255u] = sc.srgb_lut[threadIdx.x & 255u]; __syncthreads(); }
-PT_DEV float srgb_decode(const float*, uint32_t i) { return pt_lds_srgb[i]; }
+static __shared__ float pt_lds_lut[512];               // [0,256) sRGB decode, [256,512) sheen directional albedo 16x16
+PT_DEV void stage_luts(const SceneRec& sc) {           // 256-thread workgroups
+    pt_lds_lut[threadIdx.x & 255u] = sc.srgb_lut[threadIdx.x & 255u];
+    pt_lds_lut[256u + (threadIdx.x & 255u)] = sc.sheen_e[threadIdx.x & 255u];
+    __syncthreads();
+}
+PT_DEV float srgb_decode(const float*, uint32_t i) { return pt_lds_lut[i]; }
+PT_DEV float sheen_entry(const float*, int i) { return pt_lds_lut[256 + i]; }
 #else
 PT_DEV void stage_luts(const SceneRec&) {}
 PT_DEV float srgb_decode(const float* lut, uint32_t i) { return lut[i]; }
+PT_DEV float sheen_entry(const float* lut, int i) { return lut[i]; }
 #endif
 PT_DEV vec4 unpack_texel(uint32_t t, uint32_t srgb, const float* lut) {
     uint32_t r = t & 0xff, g = (t >> 8) & 0xff, b = (t >> 16) & 0xff, a = t >> 24;
@@ -426,7 +432,7 @@ PT_DEV float sheen_e(const float* lut, float alpha, float cos_theta) {   // Bsdf
     int ia = max(i0, 0), ib = min(i0 + 1, 15), ja = max(j0, 0), jb = min(j0 + 1, 15);
     ia = min(ia, 15); ja = min(ja, 15); ib = max(ib, 0); jb = max(jb, 0);
     float w00 = (1 - fx) * (1 - fy), w10 = fx * (1 - fy), w01 = (1 - fx) * fy, w11 = fx * fy;
-    return lut[ja * 16 + ia] * w00 + lut[ja * 16 + ib] * w10 + lut[jb * 16 + ia] * w01 + lut[jb * 16 + ib] * w11;
+    return sheen_entry(lut, ja * 16 + ia) * w00 + sheen_entry(lut, ja * 16 + ib) * w10 + sheen_entry(lut, jb * 16 + ia) * w01 + sheen_entry(lut, jb * 16 + ib) * w11;
 }
 PT_DEV float modulate_roughness(float a, float ior) { return clampf(lerpf(0, a, saturate(2 * (ior - 1))), kMinRoughness, 1.0f); }   // :216-220
 
@@ -461,7 +467,10 @@ PT_DEV vec3 gltf_bsdf(const float* lut, const Surface& s, vec3 v, vec3 l, int mo
     float sa = clampf(s.sheen_a, 0.000001f, 1);
     vec3 sheen = refl ? v3(saturate(ll.z) * sheen_brdf(sa, ll.z, vl.z, hl.z)) : v3(0);
     float ms = max3(s.sheen_color);                                               // SheenMix :210-214
-    float scaling = hmin(1.0f - ms * sheen_e(lut, sa, vl.z), 1.0f - ms * sheen_e(lut, sa, ll.z));
+    // Without sheen (ms == 0) both terms are 1 - 0 * E = 1 exactly (E is always finite: sheen_e clamps NaN coordinates):
+    // skip the eight table gathers.
+    float scaling = 1.0f;
+    if (ms != 0.0f) scaling = hmin(1.0f - ms * sheen_e(lut, sa, vl.z), 1.0f - ms * sheen_e(lut, sa, ll.z));
     material = s.sheen_color * sheen + material * scaling;
     float cndv = dot(n, v), cndh = dot(n, h), cndl = dot(n, l);                    // (sic) shading normal
     float cc = refl ? saturate(cndl) * specular_brdf(s.cc_rough, cndl, cndv, cndh, hdl, hdv) : 0.f;
