@@ -13,11 +13,11 @@ barrier + torch.cuda.synchronize on both sides; time = max over ranks.  value = 
 ranks in the K steps / that time.  Rays are counted by the kernel itself (every traversal started).
 
 Extra objects on the JSON line:
-  roofline     - dominant kernel pt_megakernel: algorithmic bytes per launch (counted by an untimed
-                 instrumented replay of the same K frames: nodes*64 + tris*48 + hits*S_hit + taps*16
-                 + env loads + 32 B/pixel) / mean kernel time measured live with HIP events on the
-                 launch stream; peak = 8 TB/s HBM; traffic = PMC-measured HBM bytes per launch from
-                 profiles/ (same command), or null.
+  roofline     - the wavefront pipeline of one pt_trace (one launch = one frame): algorithmic bytes per
+                 launch (counted by an untimed instrumented replay of the same K frames: nodes*128 +
+                 tris*48 + hits*S_hit + taps*16 + env loads + 32 B/pixel) / mean per-frame kernel time
+                 measured live with HIP events on the launch stream; peak = 8 TB/s HBM; traffic =
+                 PMC-measured HBM bytes per launch from profiles/pmc_traffic.json (same command), or null.
   cpu_baseline - the CPU oracle (kind "port": the reference has no CPU tracer) on a bounded sample of
                  the same workload, all host cores.
 """
@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--stage-blocks", type=int, default=0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --single-device rehearses N ranks on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (RCCL needs one device per rank)")
+    ap.add_argument("--animate", action="store_true", help="config 5 (--config figure): skin -> BVH rebuild -> trace every step, accumulation reset each frame")
     args = ap.parse_args()
 
     import numpy as np
@@ -89,6 +90,12 @@ def main():
     r = Renderer(device=local_rank)
     r.set_kernel_mode(abi.MODE_MEGAKERNEL if args.mode == "megakernel" else abi.MODE_WAVEFRONT, args.stage_blocks)
     h = s.upload(r)
+    binding = None
+    if args.animate:
+        if not s.skins:
+            raise SystemExit("--animate needs a scene with a skinned mesh (--config figure)")
+        binding = scenes.SkinBinding(r, s, h, 0, use_mfma=1)      # every rank skins and rebuilds itself
+        binding.pose(0.0)
     r.build_accel()
     settings = s.settings
     out = r.create_output(s.width, s.height)
@@ -105,7 +112,14 @@ def main():
         else:
             reduce_frame(img, world)        # one RCCL reduce(sum) of the accumulation buffer over xGMI
 
+    def animate(frame):
+        if binding is not None:           # Main.cpp:521-523: a playing animation resets accumulation every frame
+            binding.pose((frame % 60) / 30.0)
+            r.build_accel()
+            settings.reset = 1
+
     def step(frame):
+        animate(frame)
         if world > 1:
             out.zero_()
             settings.reset = 1          # each step is a fresh 1-spp frame when sharded (the reduce sums disjoint tiles)
@@ -128,6 +142,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         frame = args.warmup + k
+        animate(frame)
         if world > 1:
             out.zero_()
             settings.reset = 1
@@ -168,6 +183,18 @@ def main():
                        "rays_per_frame": round(rays_total / args.steps, 1), "bvh_build_ms": round(accel_ms, 3), "scene_setup_s": round(t_setup, 1)},
         }
 
+    # ---- config 5: skin / BVH rebuild / trace split, measured on an untimed synchronised replay of a few frames
+    if rank == 0 and binding is not None:
+        parts = {"skin_ms": [], "accel_ms": [], "trace_ms": []}
+        for k in range(min(args.steps, 8)):
+            animate(args.warmup + k)
+            r.trace(settings, s.execute_params(frame=args.warmup + k, tile_rank=rank, tile_rank_count=world, env_handle=h["env"]), out)
+            torch.cuda.synchronize()
+            st2 = r.stats()
+            parts["skin_ms"].append(st2.skin_ms); parts["accel_ms"].append(st2.accel_ms); parts["trace_ms"].append(st2.trace_ms)
+        result["config"]["dynamic_ms"] = {k2: round(sum(v) / len(v), 4) for k2, v in parts.items()}
+        result["config"]["parallelism"] += "; skin (MFMA joint blend) + full LBVH rebuild + 1 spp trace per step"
+
     # ---- roofline: instrumented untimed replay of the same frames (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.no_roofline:
         r.enable_counters(True)
@@ -176,6 +203,9 @@ def main():
         torch.cuda.synchronize()
         r.reset_stats()
         for k in range(args.steps):
+            animate(args.warmup + k)
+            if binding is not None:
+                settings2.reset = 1
             p = s.execute_params(frame=args.warmup + k, env_handle=h["env"])
             r.trace(settings2, p, out2)
         c = r.stats()
@@ -191,7 +221,7 @@ def main():
         achieved = alg / (mean_ms * 1e-3) / 1e9
         traffic = None
         pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pj):
+        if os.path.exists(pj) and args.config == "sponza" and not (args.width or args.height or args.animate) and args.mode == "wavefront":
             try:
                 traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
             except Exception:

@@ -602,3 +602,38 @@ def bones_for_pose(skin, node_global, joint_globals):
         b.inverse_transpose[:] = camera.cm(it)
         out.append(b)
     return out
+
+
+class SkinBinding:
+    """The per-frame dynamic-mesh step of Renderer::DrawFrame for one skinned instance (Renderer.cpp:399-457,
+    Pathtracer.cpp:235-240): output streams, GpuSkin::Run parameters, and the instance table re-pointed at them."""
+
+    def __init__(self, backend, scene, handles, skin_index=0, use_mfma=1):
+        sk = scene.skins[skin_index]
+        mesh = sk["mesh"]
+        self.backend, self.skin = backend, sk
+        self.out_position = backend.buffer_create(None, abi.FORMAT_R32G32B32_FLOAT, mesh.num_vertices * 12)
+        self.out_tangent_space = backend.buffer_create(None, abi.FORMAT_R10G10B10A2_UNORM, mesh.num_vertices * 4)
+        p = abi.PtSkinParams()
+        p.num_of_vertices = mesh.num_vertices
+        p.input_mesh_flags = abi.MESH_FLAG_INDEX | abi.MESH_FLAG_TANGENT_SPACE | abi.MESH_FLAG_TEXCOORD_0 | abi.MESH_FLAG_JOINT_WEIGHT
+        p.output_mesh_flags = abi.DYNAMIC_MESH_FLAG_POSITION | abi.DYNAMIC_MESH_FLAG_TANGENT_SPACE
+        p.input_position = handles["buffers"][sk["input_position"]]
+        p.input_tangent_space = handles["buffers"][sk["input_tangent_space"]]
+        p.input_joint_weight = handles["buffers"][sk["joint_weight"]]
+        p.output_position, p.output_tangent_space = self.out_position, self.out_tangent_space
+        p.num_of_morph_targets = 0
+        for i in range(4):
+            p.morph_position[i] = -1
+            p.morph_tangent_space[i] = -1
+        p.use_mfma = int(use_mfma)
+        self.params = p
+        inst = [abi.PtInstanceDesc.from_buffer_copy(bytes(d)) for d in handles["instances"]]
+        inst[sk["instance"]].gpu.position_descriptor = self.out_position
+        inst[sk["instance"]].gpu.tangent_space_descriptor = self.out_tangent_space
+        self.instances = inst
+        backend.set_instances(inst)
+
+    def pose(self, t):
+        """Skin the mesh to the walk-cycle pose at time t (seconds); the caller rebuilds the acceleration structure."""
+        self.backend.skin_run(self.params, bones_for_pose(self.skin, np.eye(4), skinned_figure_pose(t)))

@@ -247,25 +247,10 @@ def test_tonemap_matches_oracle(pair):
 
 
 def _skin_setup(backend, s, use_mfma, t):
-    sk = s.skins[0]
     h = s.upload(backend)
-    mesh = sk["mesh"]
-    out_pos = backend.buffer_create(None, abi.FORMAT_R32G32B32_FLOAT, mesh.num_vertices * 12)
-    out_ts = backend.buffer_create(None, abi.FORMAT_R10G10B10A2_UNORM, mesh.num_vertices * 4)
-    p = abi.PtSkinParams()
-    p.num_of_vertices = mesh.num_vertices
-    p.input_mesh_flags = abi.MESH_FLAG_INDEX | abi.MESH_FLAG_TANGENT_SPACE | abi.MESH_FLAG_TEXCOORD_0 | abi.MESH_FLAG_JOINT_WEIGHT
-    p.output_mesh_flags = abi.DYNAMIC_MESH_FLAG_POSITION | abi.DYNAMIC_MESH_FLAG_TANGENT_SPACE
-    p.input_position = h["buffers"][sk["input_position"]]
-    p.input_tangent_space = h["buffers"][sk["input_tangent_space"]]
-    p.input_joint_weight = h["buffers"][sk["joint_weight"]]
-    p.output_position, p.output_tangent_space = out_pos, out_ts
-    p.num_of_morph_targets = 0
-    for i in range(4):
-        p.morph_position[i] = -1; p.morph_tangent_space[i] = -1
-    p.use_mfma = int(use_mfma)
-    bones = scenes.bones_for_pose(sk, np.eye(4), scenes.skinned_figure_pose(t))
-    backend.skin_run(p, bones)
+    bind = scenes.SkinBinding(backend, s, h, 0, use_mfma)
+    bind.pose(t)
+    mesh, p, out_pos, out_ts = s.skins[0]["mesh"], bind.params, bind.out_position, bind.out_tangent_space
     return (backend.buffer_read(out_pos, np.float32, mesh.num_vertices * 3).reshape(-1, 3), backend.buffer_read(out_ts, np.uint32, mesh.num_vertices),
             h, p, out_pos, out_ts)
 
@@ -296,10 +281,6 @@ def test_skinned_frame_renders_like_oracle(R, oracle_lib):
     outs = []
     for backend in (R(), oracle_lib.Oracle()):
         pos, ts, h, p, out_pos, out_ts = _skin_setup(backend, s, 0, 0.8)
-        inst = [abi.PtInstanceDesc.from_buffer_copy(bytes(d)) for d in h["instances"]]
-        inst[s.skins[0]["instance"]].gpu.position_descriptor = out_pos            # BuildTlas: dynamic mesh streams (Pathtracer.cpp:235-240)
-        inst[s.skins[0]["instance"]].gpu.tangent_space_descriptor = out_ts
-        backend.set_instances(inst)
         outs.append((backend, h))
     (r, hg), (o, ho) = outs
     o2 = oracle_lib.Oracle()      # oracle must see the GPU-preprocessed env: re-create with raw maps
