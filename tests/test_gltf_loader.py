@@ -1,0 +1,602 @@
+"""N1 / N2 / N4 rows: the C++ glTF/GLB loader, image readers and animation sampler of libmipt.so
+against the numpy restatement in oracle/gltf_oracle.py, on synthetic files written by tests/gltf_writer.py.
+Host-only: no GPU is needed (the loader is plain C++ behind include/mipt_scene.h).
+
+PARITY UNPINNED against tinygltf / stb_image / tinyexr (absent upstream and here): what is pinned is the reference's OWN
+conversion rules (TinyGltfTools.h, Gltf.cpp, Animation.cpp) as restated by the oracle, bit-exact for integer / byte streams.
+"""
+import io
+import json
+import math
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from gltf_renderer_amd import abi, meshgen
+from gltf_renderer_amd import gltf as G
+from gltf_renderer_amd.renderer import MiptError
+from oracle import gltf_oracle as O
+from tests.gltf_writer import Builder
+
+PIL = pytest.importorskip("PIL.Image")
+
+
+def png_bytes(arr, mode=None, **kw):
+    b = io.BytesIO()
+    PIL.fromarray(arr, mode).save(b, "PNG", **kw)
+    return b.getvalue()
+
+
+def pil_png(im, **kw):
+    b = io.BytesIO()
+    im.save(b, "PNG", **kw)
+    return b.getvalue()
+
+
+def jpeg_bytes(arr, **kw):
+    b = io.BytesIO()
+    PIL.fromarray(arr).save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+def smooth_image(rng, h, w, c):
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    chans = [127 + 100 * np.sin(xx / (5 + 3 * k) + k) * np.cos(yy / (7 + 2 * k)) + rng.normal(0, 4, (h, w)) for k in range(c)]
+    return np.clip(np.stack(chans, -1), 0, 255).astype(np.uint8)
+
+
+def build_kitchen_sink(embed):
+    rng = np.random.default_rng(7)
+    b = Builder()
+    # ---- images: every decoder path
+    rgb = smooth_image(rng, 40, 56, 3)
+    rgba = smooth_image(rng, 33, 47, 4)
+    img = {}
+    img["png_rgba"] = b.image(png_bytes(rgba), "image/png", "png_rgba", embed)
+    img["png_rgb"] = b.image(png_bytes(rgb), "image/png", "png_rgb", embed)
+    img["png_gray"] = b.image(png_bytes(rgb[..., 0]), "image/png", "png_gray", embed)
+    img["png_pal"] = b.image(pil_png(PIL.fromarray(rgb).quantize(16)), "image/png", "png_pal", embed)
+    img["png_interlaced"] = b.image(png_bytes(rgba[::-1].copy()), "image/png", "png_i", embed)
+    img["png_16"] = b.image(pil_png(PIL.fromarray(rgb[..., 0].astype(np.uint16) * 257)), "image/png", "png_16", embed)
+    img["jpg_420"] = b.image(jpeg_bytes(rgb, quality=92, subsampling=2), "image/jpeg", "jpg_420", embed)
+    img["jpg_444"] = b.image(jpeg_bytes(rgb, quality=95, subsampling=0), "image/jpeg", "jpg_444", embed)
+    img["jpg_422"] = b.image(jpeg_bytes(rgb, quality=90, subsampling=1), "image/jpeg", "jpg_422", embed)
+    img["jpg_prog"] = b.image(jpeg_bytes(rgb, quality=90, progressive=True), "image/jpeg", "jpg_prog", embed)
+    img["jpg_gray"] = b.image(jpeg_bytes(rgb[..., 1], quality=90), "image/jpeg", "jpg_gray", embed)
+    img["unused"] = b.image(png_bytes(rgb), "image/png", "unused", embed)
+    s_clamp = b.sampler(wrapS=33071, wrapT=33648, magFilter=9729, minFilter=9987)
+    s_point = b.sampler(magFilter=9728, minFilter=9728)
+    tex = {k: b.texture(v, s_clamp if i % 3 == 1 else (s_point if i % 3 == 2 else None)) for i, (k, v) in enumerate(img.items())}
+    tt = {"KHR_texture_transform": {"offset": [0.25, -0.5], "rotation": 0.35, "scale": [2.0, 0.5], "texCoord": 1}}
+    b.material({"name": "everything", "doubleSided": True, "alphaMode": "MASK", "alphaCutoff": 0.35, "emissiveFactor": [0.5, 0.25, 2.0],
+                "pbrMetallicRoughness": {"baseColorFactor": [0.9, 0.8, 0.7, 0.6], "metallicFactor": 0.4, "roughnessFactor": 0.3,
+                                         "baseColorTexture": {"index": tex["png_rgba"], "texCoord": 1, "extensions": tt},
+                                         "metallicRoughnessTexture": {"index": tex["jpg_420"]}},
+                "normalTexture": {"index": tex["png_rgb"], "scale": 0.75}, "occlusionTexture": {"index": tex["png_gray"], "strength": 0.5},
+                "emissiveTexture": {"index": tex["jpg_444"]},
+                "extensions": {"KHR_materials_anisotropy": {"anisotropyStrength": 0.6, "anisotropyRotation": 1.2, "anisotropyTexture": {"index": tex["png_pal"]}},
+                               "KHR_materials_clearcoat": {"clearcoatFactor": 0.8, "clearcoatRoughnessFactor": 0.2, "clearcoatTexture": {"index": tex["jpg_422"]},
+                                                           "clearcoatRoughnessTexture": {"index": tex["jpg_prog"], "extensions": tt},
+                                                           "clearcoatNormalTexture": {"index": tex["png_interlaced"], "scale": 0.5}},
+                               "KHR_materials_emissive_strength": {"emissiveStrength": 3.0}, "KHR_materials_ior": {"ior": 1.33},
+                               "KHR_materials_sheen": {"sheenColorFactor": [0.1, 0.2, 0.3], "sheenRoughnessFactor": 0.45, "sheenColorTexture": {"index": tex["jpg_gray"]},
+                                                       "sheenRoughnessTexture": {"index": tex["png_16"]}},
+                               "KHR_materials_specular": {"specularFactor": 0.7, "specularColorFactor": [0.9, 0.8, 0.95], "specularTexture": {"index": tex["png_rgba"]},
+                                                          "specularColorTexture": {"index": tex["png_rgb"]}},
+                               "KHR_materials_transmission": {"transmissionFactor": 0.25, "transmissionTexture": {"index": tex["png_gray"]}},
+                               "KHR_materials_volume": {"thicknessFactor": 0.1, "attenuationDistance": 2.0, "attenuationColor": [0.5, 0.6, 0.7],
+                                                        "thicknessTexture": {"texCoord": 1}}}})          # no index: resolves to texture 0 upstream
+    b.material({"name": "blend", "alphaMode": "BLEND", "extensions": {"KHR_materials_unlit": {}}})
+    b.material({"name": "plain"})
+    # ---- mesh 0, primitive 0: every conversion path
+    g = meshgen.grid(4, 4, (-1, -1, 0), (2, 0, 0), (0, 2, 0))
+    nv = g.num_vertices
+    uv0_u16 = np.round(np.clip(g.uv0, 0, 1) * 65535).astype(np.uint16)
+    col_u8 = rng.integers(0, 256, (nv, 3)).astype(np.uint8)
+    a_pos = b.accessor(g.positions, minmax=True)
+    a_nrm, a_tan = b.interleaved([g.normals, g.tangents])
+    a_uv0 = b.accessor(uv0_u16, normalized=True, stride=8)
+    a_uv1, a_col = b.interleaved([(g.uv0 * 3).astype(np.float32), col_u8], normalized=[False, True])
+    a_idx = b.accessor(g.indices.astype(np.uint8))
+    p0 = {"attributes": {"POSITION": a_pos, "NORMAL": a_nrm, "TANGENT": a_tan, "TEXCOORD_0": a_uv0, "TEXCOORD_1": a_uv1, "COLOR_0": a_col}, "indices": a_idx, "material": 0}
+    # ---- primitive 1: normals only, u16 indices, sparse positions, int16-normalised normals
+    iv, ifc = meshgen.icosphere(1)
+    ico = meshgen.Mesh(iv, ifc.reshape(-1), normals=iv)
+    moved = np.array([1, 5, 7], np.uint16)
+    a_pos1 = b.sparse_accessor(ico.positions, moved, (ico.positions[moved] * 1.5).astype(np.float32))
+    n_i16 = np.round(ico.normals * 32767).astype(np.int16)
+    a_nrm1 = b.accessor(n_i16, normalized=True, stride=8)
+    a_idx1 = b.accessor(ico.indices.astype(np.uint16))
+    p1 = {"attributes": {"POSITION": a_pos1, "NORMAL": a_nrm1}, "indices": a_idx1, "material": 2}
+    # ---- primitive 2: non-indexed float colours (RGBA), sparse accessor without a base view; primitive 3: triangle fan (skipped)
+    tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [0, 1, 1]], np.float32)
+    a_pos2 = b.sparse_accessor(np.zeros_like(tri), np.array([1, 2, 3, 4, 5], np.uint8), tri[1:], with_base=False)
+    a_col2 = b.accessor(rng.random((6, 4)).astype(np.float32))
+    p2 = {"attributes": {"POSITION": a_pos2, "COLOR_0": a_col2}}
+    p3 = {"attributes": {"POSITION": a_pos}, "mode": 6}
+    m0 = b.mesh([p0, p1, p2, p3], name="static")
+    # ---- mesh 1: skinned + morphed tube
+    tube, tf = meshgen.capsule_tube((0, 0, 0), (0, 0, 2), 0.2, nseg=8, nring=4)
+    tv = tube.num_vertices
+    joints = np.stack([np.zeros(tv), np.ones(tv), np.full(tv, 2), np.zeros(tv)], 1).astype(np.uint8)
+    w = np.stack([1 - tf, tf * 0.7, tf * 0.3, np.zeros(tv)], 1).astype(np.float32)
+    d1 = (rng.normal(0, 0.05, (tv, 3))).astype(np.float32)
+    d2 = (tube.normals * 0.1).astype(np.float32)
+    prim = {"attributes": {"POSITION": b.accessor(tube.positions, minmax=True), "NORMAL": b.accessor(tube.normals), "TEXCOORD_0": b.accessor(tube.uv0),
+                           "JOINTS_0": b.accessor(joints), "WEIGHTS_0": b.accessor(w)}, "indices": b.accessor(tube.indices.astype(np.uint32)), "material": 1,
+            "targets": [{"POSITION": b.accessor(d1), "NORMAL": b.accessor(rng.normal(0, 0.2, (tv, 3)).astype(np.float32))}, {"POSITION": b.accessor(d2)}]}
+    m1 = b.mesh([prim], weights=[0.25, 0.0], name="skinned")
+    # ---- nodes
+    q = lambda ax, ang: [ax[0] * math.sin(ang / 2), ax[1] * math.sin(ang / 2), ax[2] * math.sin(ang / 2), math.cos(ang / 2)]
+    c, s_ = math.cos(0.4), math.sin(0.4)
+    mat = [2 * c, 2 * s_, 0, 0, -1.5 * s_, 1.5 * c, 0, 0, 0, 0, 0.5, 0, 1.0, 2.0, 3.0, 1]             # T * Rz(0.4) * S(2, 1.5, 0.5), column-major
+    n_static = b.node(mesh=m0, name="static", matrix=mat)
+    j2 = b.node(name="j2", translation=[0, 0.9, 0], rotation=q((1, 0, 0), 0.3))
+    j1 = b.node(name="j1", translation=[0, 1.0, 0], rotation=q((0, 0, 1), -0.2), children=[j2])
+    j0 = b.node(name="j0", translation=[0.5, 0, 0], children=[j1])
+    ibm = np.stack([np.linalg.inv(np.array(m, np.float64)).T.reshape(16) for m in (np.eye(4), np.eye(4) + np.diag([0, 0, 0, 0]), np.eye(4))]).astype(np.float32)
+    ibm[1, 13] = -1.0
+    ibm[2, 13] = -1.9
+    b.j["skins"] = [{"joints": [j0, j1, j2], "inverseBindMatrices": b.accessor(ibm.reshape(3, 16))}]
+    n_skin = b.node(mesh=m1, skin=0, name="skinned", translation=[-2, 0, 0], weights=[0.1, 0.7])
+    b.j.setdefault("extensions", {})["KHR_lights_punctual"] = {"lights": [
+        {"type": "point", "intensity": 40.0, "color": [1.0, 0.9, 0.8], "range": 12.0}, {"type": "directional", "intensity": 3.0},
+        {"type": "spot", "intensity": 100.0, "spot": {"innerConeAngle": 0.2, "outerConeAngle": 0.5}}]}
+    l0 = b.node(name="lp", translation=[1, 4, 2], extensions={"KHR_lights_punctual": {"light": 0}})
+    l1 = b.node(name="ld", rotation=q((1, 0, 0), -0.9), extensions={"KHR_lights_punctual": {"light": 1}})
+    l2 = b.node(name="ls", translation=[0, 5, 0], rotation=q((0.6, 0.8, 0), 1.1), scale=[1, 2, 1], extensions={"KHR_lights_punctual": {"light": 2}})
+    root = b.node(root=True, name="root", children=[n_static, j0, n_skin, l0, l1, l2], scale=[1, 1, 1])
+    b.j["extensionsUsed"] = ["KHR_lights_punctual", "KHR_texture_transform", "KHR_materials_ior"]
+    b.j["extensionsRequired"] = ["KHR_lights_punctual", "KHR_texture_transform"]
+    # ---- animation: every path / interpolation / a normalised format
+    t_in = b.accessor(np.array([0.0, 0.5, 1.0, 2.0], np.float32), minmax=True)
+    tr = b.accessor(rng.normal(0, 1, (4, 3)).astype(np.float32))
+    rots = np.array([q((0, 0, 1), a) for a in (0.0, 0.8, -0.4, 2.5)], np.float32)
+    rot_f = b.accessor(rots)
+    rot_u8 = b.accessor(np.round((np.abs(rots)) * 255).astype(np.uint8), normalized=True)
+    sc = b.accessor(np.array([[1, 1, 1], [2, 1, 1], [1, 3, 1], [1, 1, 0.5]], np.float32))
+    wts = b.accessor(np.array([0, 0, 1, 0, 0.5, 0.5, 0, 1], np.float32))
+    cub_in = b.accessor(np.array([0.0, 1.0, 3.0], np.float32), minmax=True)
+    cub = b.accessor(rng.normal(0, 1, (9, 3)).astype(np.float32))
+    b.j["animations"] = [{"name": "all", "samplers": [{"input": t_in, "output": tr, "interpolation": "LINEAR"}, {"input": t_in, "output": rot_f},
+                                                       {"input": t_in, "output": sc, "interpolation": "STEP"}, {"input": t_in, "output": wts},
+                                                       {"input": cub_in, "output": cub, "interpolation": "CUBICSPLINE"}, {"input": t_in, "output": rot_u8}],
+                          "channels": [{"sampler": 0, "target": {"node": j1, "path": "translation"}}, {"sampler": 1, "target": {"node": j1, "path": "rotation"}},
+                                       {"sampler": 2, "target": {"node": j2, "path": "scale"}}, {"sampler": 3, "target": {"node": n_skin, "path": "weights"}},
+                                       {"sampler": 4, "target": {"node": j0, "path": "translation"}}, {"sampler": 5, "target": {"node": j2, "path": "rotation"}}]}]
+    return b
+
+
+@pytest.fixture(scope="module", params=["glb", "gltf_data_uri", "gltf_external"])
+def sink(request, tmp_path_factory):
+    d = tmp_path_factory.mktemp("gltf_" + request.param)
+    if request.param == "glb":
+        path = build_kitchen_sink("view").write_glb(str(d / "sink.glb"))
+    elif request.param == "gltf_data_uri":
+        path = build_kitchen_sink("uri").write_gltf(str(d / "sink.gltf"))
+    else:
+        path = build_kitchen_sink("file").write_gltf(str(d / "sink with space.gltf"), external_bin=True)
+    return path, G.GltfScene(path), O.Doc(path)
+
+
+def ts_close(a, b):
+    """packed 10-10-10-2 streams: identical up to one quantisation step on a rounding edge (libm vs numpy atan2 / sqrt)."""
+    if a is None or b is None:
+        return a is None and b is None
+    a, b = a.astype(np.int64), b.astype(np.int64)
+    ok = True
+    for sh in (0, 10):
+        ok &= np.abs(((a >> sh) & 1023) - ((b >> sh) & 1023)).max() <= 1
+    ang = np.abs(((a >> 20) & 1023) - ((b >> 20) & 1023))
+    ok &= np.minimum(ang, 1023 - ang).max() <= 1
+    return bool(ok and np.all((a >> 30) == (b >> 30)) and np.mean(a == b) > 0.97)
+
+
+def test_streams_bit_exact_against_the_reference_conversion_rules(sink):
+    path, sc, doc = sink
+    c = sc.counts()
+    assert (c.meshes, c.primitives, c.materials, c.skins, c.animations, c.lights, c.samplers, c.textures) == (2, 5, 4, 1, 1, 3, 2, 12)
+    flat = 0
+    for mi, gm in enumerate(doc.j["meshes"]):
+        for gp in gm["primitives"]:
+            o = O.load_primitive(doc, gp, meshgen.encode_tangent_space, meshgen.encode_normal)
+            p = sc.primitive(flat)
+            if not o.get("valid", True):
+                assert p["flags"] == 0 and p["topology"] == 6            # triangle fan: skipped (Gltf.cpp:201-204)
+                flat += 1
+                continue
+            assert p["mesh"] == mi and p["flags"] == o["flags"] and p["num_vertices"] == o["num_vertices"] and p["material_id"] == o["material_id"]
+            for k in ("index", "position", "texcoord0", "texcoord1", "color", "joint_weight"):
+                if o[k] is None:
+                    assert p[k] is None, k
+                else:
+                    assert p[k].dtype == o[k].dtype and np.array_equal(p[k], o[k].reshape(p[k].shape)), (flat, k)
+            assert ts_close(p["tangent_space"], o["tangent_space"])
+            for t, ot in enumerate(o["targets"]):
+                fl, pos, ts = sc.morph_target(flat, t, p["num_vertices"])
+                assert (pos is None) == (ot["position"] is None) and (pos is None or np.array_equal(pos, ot["position"]))
+                assert ts_close(ts, ot["tangent_space"])
+            flat += 1
+    p0 = sc.primitive(0)
+    assert p0["index_format"] == abi.FORMAT_R16_UINT and p0["index"].dtype == np.uint16           # u8 indices widened
+    assert np.all(p0["color"][:, 3] == 1)                                                         # missing alpha = (uint16)1, not 65535 (TinyGltfTools.h:217-219)
+    assert sc.primitive(2)["index"] is None and np.array_equal(sc.primitive(2)["position"][0], [0, 0, 0])
+    assert sc.primitive(4)["index_format"] == abi.FORMAT_R32_UINT
+
+
+SLOTS = ["normal", "albedo", "metallic_roughness", "occlusion", "emissive", "specular", "specular_color", "clearcoat", "clearcoat_roughness", "clearcoat_normal",
+         "anisotropy", "sheen_color", "sheen_roughness", "transmission", "thickness"]
+
+
+def test_materials_textures_and_samplers(sink):
+    path, sc, doc = sink
+    ml = O.MaterialLoader(doc)
+    mats = ml.load()
+    assert sc.counts().materials == len(mats) == 4
+    for i, om in enumerate(mats):
+        m = sc.material(i)
+        for k in ("flags", "alpha_mode"):
+            assert getattr(m, k) == om[k], (i, k)
+        for k in ("metalness_factor", "roughness_factor", "occlusion_factor", "alpha_cutoff", "ior", "normal_scale", "specular_factor", "clearcoat_factor",
+                  "clearcoat_roughness_factor", "clearcoat_normal_scale", "anisotropy_strength", "anisotropy_rotation", "sheen_roughness_factor",
+                  "transmission_factor", "thickness_factor", "attenuation_distance"):
+            assert getattr(m, k) == np.float32(om[k]), (i, k)
+        for k in ("base_color_factor", "emissive_factor", "specular_color_factor", "sheen_color_factor", "attenuation_color"):
+            assert np.array_equal(np.array(getattr(m, k)[:], np.float32), np.array(om[k], np.float32)), (i, k)
+        for k in SLOTS:
+            t, ot = getattr(m, k), om[k]
+            assert (t.descriptor, t.sampler, t.tex_coord) == (ot["texture"], ot["sampler"], ot["tex_coord"]), (i, k)
+            assert t.rotation == np.float32(ot["rotation"]) and tuple(t.offset[:]) == tuple(np.float32(ot["offset"])) and tuple(t.scale[:]) == tuple(np.float32(ot["scale"])), (i, k)
+    m1 = sc.material(1)
+    assert tuple(m1.emissive_factor[:]) == (np.float32(1.5), np.float32(0.75), np.float32(6.0))          # pre-multiplied by emissive_strength (Renderer.h:137)
+    assert m1.thickness.descriptor == 0 and m1.thickness.tex_coord == 1                                 # extension texture without index -> texture 0 (Gltf.cpp:456-457)
+    assert sc.material(2).alpha_cutoff == 0.0 and sc.material(2).flags == 2                             # cutoff forced to 0 unless MASK; unlit flag
+    # lazily decoded images carry the sRGB flag of their FIRST reference; unreferenced images are never decoded
+    for i in range(sc.counts().textures):
+        t = sc.texture(i)
+        assert t["loaded"] == (i in ml.first_use_srgb), i
+        if t["loaded"]:
+            assert t["srgb"] == ml.first_use_srgb[i], i
+    s0, s1 = sc.sampler(0), sc.sampler(1)
+    assert (s0.address_u, s0.address_v, s0.min_filter, s0.mag_filter) == (abi.ADDRESS_CLAMP, abi.ADDRESS_MIRROR, abi.FILTER_LINEAR, abi.FILTER_LINEAR)
+    assert (s1.address_u, s1.address_v, s1.min_filter, s1.mag_filter) == (abi.ADDRESS_WRAP, abi.ADDRESS_WRAP, abi.FILTER_POINT, abi.FILTER_POINT)
+
+
+def test_png_exact_and_jpeg_close_to_an_independent_decoder(sink):
+    path, sc, doc = sink
+    names = [im["name"] for im in doc.j["images"]]
+    for i, name in enumerate(names):
+        t = sc.texture(i)
+        if not t["loaded"]:
+            continue
+        ref = O.decode_image(doc, i)
+        assert t["rgba"].shape == ref.shape, name
+        if name.startswith("png"):
+            assert np.array_equal(t["rgba"], ref), name
+        else:           # JPEG: stb-style integer IDCT / chroma filter vs libjpeg-turbo
+            d = np.abs(t["rgba"].astype(int) - ref.astype(int))
+            assert d[..., 3].max() == 0 and d.mean() < 1.0 and d.max() <= 12, (name, d.mean(), d.max())
+
+
+def test_png_variants_decode_exactly():
+    rng = np.random.default_rng(3)
+    rgba = rng.integers(0, 256, (19, 23, 4)).astype(np.uint8)
+    cases = {"rgba": png_bytes(rgba), "rgb": png_bytes(rgba[..., :3]), "gray": png_bytes(rgba[..., 0]), "gray_alpha": png_bytes(rgba[..., :2], "LA"),
+             "bilevel": png_bytes((rgba[..., 0] > 127), None), "compress0": png_bytes(rgba, compress_level=0), "compress9": png_bytes(rgba, compress_level=9)}
+    pal = PIL.fromarray(rgba[..., :3]).quantize(7)
+    bb = io.BytesIO(); pal.save(bb, "PNG", transparency=2); cases["palette_trns"] = bb.getvalue()
+    g16 = (rng.integers(0, 65536, (9, 11))).astype(np.uint16)
+    bb = io.BytesIO(); PIL.fromarray(g16).save(bb, "PNG"); cases["gray16"] = bb.getvalue()
+    for name, data in cases.items():
+        got = G.decode_rgba8(data)
+        ref = np.asarray(PIL.open(io.BytesIO(data)).convert("RGBA")) if name != "gray16" else None
+        if name == "gray16":
+            ref = np.stack([(g16 >> 8).astype(np.uint8)] * 3 + [np.full(g16.shape, 255, np.uint8)], -1)      # high byte, as stb reduces 16 -> 8
+        assert np.array_equal(got, ref), name
+    # hand-made Adam7 interlaced file (PIL cannot write one): 5x3 RGB
+    img = rng.integers(0, 256, (3, 5, 3)).astype(np.uint8)
+    xs, ys, dx, dy = [0, 4, 0, 2, 0, 1, 0], [0, 0, 4, 0, 2, 0, 1], [8, 8, 4, 4, 2, 2, 1], [8, 8, 8, 4, 4, 2, 2]
+    raw = b""
+    for p in range(7):
+        sub = img[ys[p]::dy[p], xs[p]::dx[p]]
+        if sub.size:
+            raw += b"".join(b"\0" + row.tobytes() for row in sub)
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 5, 3, 8, 2, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+    assert np.array_equal(G.decode_rgba8(png)[..., :3], img)
+    with pytest.raises(MiptError):
+        G.decode_rgba8(cases["rgba"][:60])
+    with pytest.raises(MiptError):
+        G.decode_rgba8(b"not an image at all")
+
+
+def test_jpeg_restart_intervals_and_odd_sizes():
+    rng = np.random.default_rng(5)
+    for (h, w), kw in [((17, 31), dict(quality=90, subsampling=2)), ((8, 8), dict(quality=75, subsampling=0)), ((1, 1), dict(quality=90)),
+                       ((50, 35), dict(quality=85, subsampling=1, progressive=True)), ((33, 65), dict(quality=95, subsampling=2, optimize=True))]:
+        img = smooth_image(rng, h, w, 3)
+        data = jpeg_bytes(img, **kw)
+        got, ref = G.decode_rgba8(data), np.asarray(PIL.open(io.BytesIO(data)).convert("RGBA"))
+        d = np.abs(got.astype(int) - ref.astype(int))
+        assert got.shape == ref.shape and d.mean() < 1.5 and d.max() <= 16, ((h, w), kw, d.mean(), d.max())
+    img = smooth_image(rng, 48, 64, 3)
+    bb = io.BytesIO(); PIL.fromarray(img).save(bb, "JPEG", quality=90, restart_marker_blocks=2)
+    got, ref = G.decode_rgba8(bb.getvalue()), np.asarray(PIL.open(io.BytesIO(bb.getvalue())).convert("RGBA"))
+    assert np.abs(got.astype(int) - ref.astype(int)).mean() < 1.5
+
+
+def test_node_tree_transforms_lights_and_bones(sink):
+    path, sc, doc = sink
+    nodes = doc.j["nodes"]
+    roots = sc.scene_nodes(0)
+    assert roots == doc.j["scenes"][0]["nodes"]
+    for i, gn in enumerate(nodes):                                                                   # child / sibling binary tree (Gltf.cpp:697-703)
+        n = sc.node(i)
+        ch = gn.get("children", [])
+        assert n.child == (ch[0] if ch else -1)
+        for a, b_ in zip(ch, ch[1:]):
+            assert sc.node(a).sibling == b_
+        assert n.mesh == gn.get("mesh", -1) and n.skin == gn.get("skin", -1)
+        assert n.light == gn.get("extensions", {}).get("KHR_lights_punctual", {}).get("light", -1)
+        if "matrix" not in gn:
+            assert np.allclose(n.rest_translation[:], gn.get("translation", [0, 0, 0])) and np.allclose(n.rest_rotation[:], gn.get("rotation", [0, 0, 0, 1]))
+            assert np.allclose(n.rest_scale[:], gn.get("scale", [1, 1, 1]))
+    ns = sc.node(0)                                                                                   # matrix node: glm::decompose
+    assert np.allclose(ns.rest_translation[:], [1, 2, 3]) and np.allclose(ns.rest_scale[:], [2, 1.5, 0.5], atol=1e-6)
+    assert np.allclose(ns.rest_rotation[:], [0, 0, math.sin(0.2), math.cos(0.2)], atol=1e-6)
+    sc.apply_rest_transforms()
+    sc.calculate_global_transforms(0)
+    over = {0: (list(ns.rest_translation), list(ns.rest_rotation), list(ns.rest_scale))}
+    og = O.global_transforms(doc, 0, over)
+    for i, g in og.items():
+        got = np.array(sc.node(i).global_transform[:], np.float32).reshape(4, 4).T
+        assert np.allclose(got, g, rtol=1e-6, atol=1e-6), i
+    up = np.array(sc.node(len(nodes) - 1).global_transform[:], np.float32).reshape(4, 4).T            # root: identity TRS -> the Y-up to Z-up matrix itself
+    assert np.array_equal(up, np.array([[1, 0, 0, 0], [0, 0, -1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], np.float32))
+    lights, olights = sc.gather_lights(0), O.gather_lights(doc, og, 0)
+    assert len(lights) == len(olights) == 3
+    for l, o in zip(lights, olights):
+        assert l.type == o["type"] and l.cutoff == np.float32(o["cutoff"]) and l.intensity == np.float32(o["intensity"])
+        assert np.allclose(l.position[:], o["position"], atol=1e-6) and np.allclose(l.direction[:], o["direction"], atol=1e-6)
+        assert np.allclose(l.color[:], o["color"]) and l.inner_angle == np.float32(o["inner_angle"]) and l.outer_angle == np.float32(o["outer_angle"])
+    skin_node = [i for i, gn in enumerate(nodes) if "skin" in gn][0]
+    bones, obones = sc.gather_bones(skin_node), O.gather_bones(doc, og, skin_node)
+    assert len(bones) == 3
+    for bn, (t, it) in zip(bones, obones):
+        assert np.allclose(np.array(bn.transform[:]).reshape(4, 4).T, t, atol=2e-6) and np.allclose(np.array(bn.inverse_transpose[:]).reshape(4, 4).T, it, atol=2e-6)
+    joints, ibm = sc.skin(0)
+    assert joints.tolist() == doc.j["skins"][0]["joints"] and ibm.shape == (3, 16) and ibm[1, 13] == -1.0
+    assert sc.node(skin_node).dynamic_mesh == 0 and sc.counts().dynamic_meshes == 1 and sc.node(0).dynamic_mesh == -1
+    assert np.allclose(sc.node_weights(skin_node), [0.1, 0.7])                                        # node weights beat mesh weights (Gltf.cpp:981-987)
+
+
+def test_animation_sampler_matches_animation_cpp(sink):
+    path, sc, doc = sink
+    anim = doc.j["animations"][0]
+    length, nch = sc.animation(0)
+    assert nch == 6 and length == 3.0
+    times = [-1.0, 0.0, 0.1, 0.5, 0.75, 1.0, 1.3, 1.999, 2.0, 2.7, 3.0, 9.0]
+    for ci, ch in enumerate(anim["channels"]):
+        oc = O.load_channel(doc, anim, ch)
+        info = sc.channel(0, ci)
+        assert (info["node"], info["path"], info["interpolation"], info["format"], info["width"]) == (oc["node"], oc["path"], oc["interp"], oc["format"], oc["width"])
+        assert np.array_equal(info["times"], oc["times"]) and info["transforms"].tobytes()[:len(oc["bytes"])] == oc["bytes"]
+        for t in times:
+            for fix in ([False, True] if oc["interp"] == 2 else [False]):
+                got, ref = sc.sample_channel(0, ci, t, fix, oc["width"]), O.sample_channel(oc, t, fix)
+                assert np.allclose(got, ref, rtol=2e-6, atol=2e-6), (ci, t, fix, got, ref)
+    # CUBICSPLINE: the reference reads value and tangents from element keyframe*3 (its own TODO); the fixed variant interpolates the real values
+    cub = np.frombuffer(sc.channel(0, 4)["transforms"].tobytes(), np.float32)[:27].reshape(9, 3)   # (upstream over-allocates x3, Gltf.cpp:797-799)
+    assert np.allclose(sc.sample_channel(0, 4, 1.0, False, 3), cub[3]) and np.allclose(sc.sample_channel(0, 4, 1.0, True, 3), cub[4])
+    # Animate + player: rest pose first, then channels; loop wraps with fmod, non-loop clamps and stops (AnimationPlayer.cpp:3-22)
+    j1 = [i for i, n in enumerate(doc.j["nodes"]) if n.get("name") == "j1"][0]
+    sc.animate(0, 0.75)
+    assert np.allclose(sc.node(j1).local_translation[:], O.sample_channel(O.load_channel(doc, anim, anim["channels"][0]), 0.75), atol=2e-6)
+    skin_node = [i for i, gn in enumerate(doc.j["nodes"]) if "skin" in gn][0]
+    assert np.allclose(sc.node_weights(skin_node), O.sample_channel(O.load_channel(doc, anim, anim["channels"][3]), 0.75), atol=2e-6)
+    pl = G.GsPlayer(0, 2.5, 1, 1)
+    sc.player_tick(pl, 1.0)
+    assert abs(pl.playhead - 0.5) < 1e-6 and pl.playing == 1
+    pl = G.GsPlayer(0, 2.5, 1, 0)
+    sc.player_tick(pl, 1.0)
+    assert pl.playhead == 3.0 and pl.playing == 0
+    sc.apply_rest_transforms()
+    assert np.allclose(sc.node(j1).local_translation[:], [0, 1.0, 0])
+
+
+def test_loader_errors_are_reported_not_crashes(tmp_path):
+    b = build_kitchen_sink("view")
+    b.j["extensionsRequired"] = ["KHR_draco_mesh_compression"]
+    with pytest.raises(MiptError, match="required extension"):
+        G.GltfScene(b.write_glb(str(tmp_path / "draco.glb")))
+    with pytest.raises(MiptError):
+        G.GltfScene(str(tmp_path / "missing.glb"))
+    with pytest.raises(MiptError, match="extension"):
+        G.GltfScene(str(tmp_path / "scene.obj"))
+    good = open(build_kitchen_sink("view").write_glb(str(tmp_path / "ok.glb")), "rb").read()
+    open(tmp_path / "trunc.glb", "wb").write(good[:len(good) // 2])
+    with pytest.raises(MiptError):
+        G.GltfScene(str(tmp_path / "trunc.glb"))
+    b = Builder()
+    pos = b.accessor(np.zeros((3, 3), np.float32))
+    idx = b.accessor(np.array([0, 1, 7], np.uint16))
+    b.node(root=True, mesh=b.mesh([{"attributes": {"POSITION": pos}, "indices": idx}]))
+    with pytest.raises(MiptError, match="index out of"):
+        G.GltfScene(b.write_glb(str(tmp_path / "badindex.glb")))
+    b = Builder()
+    b.j["accessors"].append({"bufferView": 5, "componentType": 5126, "count": 3, "type": "VEC3"})
+    b.node(root=True, mesh=b.mesh([{"attributes": {"POSITION": 0}}]))
+    with pytest.raises(MiptError):
+        G.GltfScene(b.write_glb(str(tmp_path / "badview.glb")))
+    open(tmp_path / "bad.gltf", "w").write('{"asset": {"version": "2.0"}, "scenes": [{"nodes": [0]}], "nodes": [{"children": [0]}]}')
+    with pytest.raises(MiptError, match="tree"):
+        G.GltfScene(str(tmp_path / "bad.gltf"))
+    open(tmp_path / "syntax.gltf", "w").write('{"asset": {"version": "2.0"}, ')
+    with pytest.raises(MiptError):
+        G.GltfScene(str(tmp_path / "syntax.gltf"))
+
+
+# ---- N2: Radiance .hdr and OpenEXR readers ---------------------------------------------------------------------------
+def rgbe_encode(rgb):
+    m = rgb.max(axis=-1)
+    e = np.where(m > 1e-32, np.floor(np.log2(np.maximum(m, 1e-38))) + 1, 0)
+    scale = np.where(m > 1e-32, 256.0 / np.exp2(e), 0)
+    out = np.zeros(rgb.shape[:-1] + (4,), np.uint8)
+    out[..., :3] = np.clip(rgb * scale[..., None], 0, 255).astype(np.uint8)
+    out[..., 3] = np.where(m > 1e-32, e + 128, 0).astype(np.uint8)
+    return out
+
+
+def rgbe_decode(px):
+    f = np.where(px[..., 3:4] != 0, np.ldexp(np.float32(1.0), px[..., 3:4].astype(np.int32) - 136), 0).astype(np.float32)
+    return (px[..., :3].astype(np.float32) * f).astype(np.float32)
+
+
+def hdr_file(px, rle):
+    h, w = px.shape[:2]
+    out = b"#?RADIANCE\n# made by a test\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0\n\n-Y %d +X %d\n" % (h, w)
+    if not rle:
+        return out + px.tobytes()
+    for y in range(h):
+        out += bytes([2, 2, w >> 8, w & 255])
+        for k in range(4):
+            row, i = px[y, :, k], 0
+            while i < w:
+                run = 1
+                while i + run < w and run < 127 and row[i + run] == row[i]:
+                    run += 1
+                if run >= 3:
+                    out += bytes([128 + run, row[i]]); i += run
+                else:
+                    j = i
+                    while j < w and j - i < 128 and not (j + 2 < w and row[j] == row[j + 1] == row[j + 2]):
+                        j += 1
+                    j = max(j, i + 1)
+                    out += bytes([j - i]) + row[i:j].tobytes(); i = j
+    return out
+
+
+def exr_file(rgb, dtype, compression, with_alpha=False, line_order=0):
+    h, w = rgb.shape[:2]
+    names = ["A", "B", "G", "R"] if with_alpha else ["B", "G", "R"]
+    planes = {"R": rgb[..., 0], "G": rgb[..., 1], "B": rgb[..., 2], "A": np.ones((h, w), np.float32)}
+    pt = 1 if dtype == np.float16 else 2
+    def attr(name, typ, data):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(data)) + data
+    chl = b"".join(n.encode() + b"\0" + struct.pack("<iBxxxii", pt, 0, 1, 1) for n in names) + b"\0"
+    hdr = struct.pack("<II", 20000630, 2) + attr("channels", "chlist", chl) + attr("compression", "compression", bytes([compression])) + \
+        attr("dataWindow", "box2i", struct.pack("<iiii", 0, 0, w - 1, h - 1)) + attr("displayWindow", "box2i", struct.pack("<iiii", 0, 0, w - 1, h - 1)) + \
+        attr("lineOrder", "lineOrder", bytes([line_order])) + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) + \
+        attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    lines = 16 if compression == 3 else 1
+    blocks = []
+    for y0 in range(0, h, lines):
+        raw = b""
+        for y in range(y0, min(y0 + lines, h)):
+            for n in names:
+                raw += planes[n][y].astype(dtype).tobytes()
+        if compression == 0:
+            data = raw
+        else:
+            a = np.frombuffer(raw, np.uint8)
+            inter = np.concatenate([a[0::2], a[1::2]])
+            d = inter.astype(np.int32)
+            pred = np.concatenate([d[:1], (d[1:] - d[:-1] + 128 + 256) % 256]).astype(np.uint8).tobytes()
+            if compression == 1:
+                data, i = b"", 0
+                while i < len(pred):
+                    run = 1
+                    while i + run < len(pred) and run < 127 and pred[i + run] == pred[i]:
+                        run += 1
+                    if run >= 3:
+                        data += struct.pack("b", run - 1) + pred[i:i + 1]; i += run
+                    else:
+                        j = i
+                        while j < len(pred) and j - i < 127 and not (j + 2 < len(pred) and pred[j] == pred[j + 1] == pred[j + 2]):
+                            j += 1
+                        j = max(j, i + 1)
+                        data += struct.pack("b", -(j - i)) + pred[i:j]; i = j
+            else:
+                data = zlib.compress(pred)
+            if len(data) >= len(raw):
+                data = raw
+        blocks.append((y0, data))
+    if line_order == 1:
+        blocks = blocks[::-1]
+    table_pos = len(hdr)
+    off = table_pos + 8 * len(blocks)
+    table, body = [None] * len(blocks), b""
+    order = sorted(range(len(blocks)), key=lambda k: blocks[k][0])
+    for k, (y0, data) in enumerate(blocks):
+        table[order.index(k) if line_order == 0 else k] = off + len(body)
+        body += struct.pack("<iI", y0, len(data)) + data
+    return hdr + b"".join(struct.pack("<Q", t) for t in table) + body
+
+
+def test_hdr_reader_rle_and_flat(tmp_path):
+    rng = np.random.default_rng(11)
+    rgb = (rng.random((13, 40, 3)) ** 4 * 5000).astype(np.float32)
+    rgb[3:6, 5:30] = 0.25                                   # runs
+    rgb[8, :, :] = 0
+    px = rgbe_encode(rgb)
+    for rle in (True, False):
+        got, half = G.decode_rgb32f(hdr_file(px, rle), False)
+        assert not half and got.dtype == np.float32 and np.array_equal(got, rgbe_decode(px)), rle
+    narrow = rgbe_encode((rng.random((4, 5, 3)) * 3).astype(np.float32))          # width < 8: always flat
+    assert np.array_equal(G.decode_rgb32f(hdr_file(narrow, False), False)[0], rgbe_decode(narrow))
+    p = tmp_path / "sky.hdr"
+    p.write_bytes(hdr_file(px, True))
+    assert np.array_equal(G.load_rgb32f(str(p))[0], rgbe_decode(px))
+    with pytest.raises(MiptError):
+        G.decode_rgb32f(b"#?RADIANCE\nFORMAT=32-bit_rle_xyze\n\n-Y 2 +X 2\n" + bytes(16), False)
+    with pytest.raises(MiptError):
+        G.decode_rgb32f(hdr_file(px, True)[:200], False)
+
+
+@pytest.mark.parametrize("compression", [0, 1, 2, 3])
+@pytest.mark.parametrize("dtype", [np.float16, np.float32])
+def test_exr_reader_scanline_images(compression, dtype):
+    rng = np.random.default_rng(13)
+    yy, xx = np.mgrid[0:37, 0:29]
+    rgb = np.stack([np.exp(np.sin(xx / 4.0) * 3), 0.5 + 0.5 * np.cos(yy / 5.0), rng.random((37, 29)) * 100], -1).astype(np.float32)
+    rgb[10:20, 3:25] = 1.0
+    for with_alpha, order in ((False, 0), (True, 1)):
+        data = exr_file(rgb, dtype, compression, with_alpha, order)
+        got, half = G.decode_rgb32f(data, True)
+        assert half == (dtype == np.float16)
+        assert np.array_equal(got, rgb.astype(dtype).astype(np.float32)), (compression, dtype, with_alpha)
+
+
+def test_exr_rejects_what_the_reference_rejects():
+    rgb = np.ones((4, 4, 3), np.float32)
+    good = exr_file(rgb, np.float32, 0)
+    tiled = good[:4] + struct.pack("<I", 2 | 0x200) + good[8:]
+    with pytest.raises(MiptError):
+        G.decode_rgb32f(tiled, True)
+    # PIZ (4): decodable only when every block is stored raw (as in the reference's own Sheen_E.exr); a shrunk block is refused
+    big = np.ones((32, 8, 3), np.float32)
+    piz_raw = exr_file(big, np.float32, 0).replace(b"compression\0compression\0\x01\0\0\0\0", b"compression\0compression\0\x01\0\0\0\x04")
+    with pytest.raises(MiptError):                                      # NONE wrote 32 one-line blocks; PIZ expects one 32-line block
+        G.decode_rgb32f(piz_raw, True)
+    with pytest.raises(MiptError, match="compression"):
+        G.decode_rgb32f(exr_file(big, np.float32, 3).replace(b"compression\0compression\0\x01\0\0\0\x03", b"compression\0compression\0\x01\0\0\0\x05"), True)
+    with pytest.raises(MiptError):
+        G.decode_rgb32f(good[:100], True)
+
+
+def test_sheen_lut_exr_of_the_reference_matches_the_committed_table():
+    """The one data fixture the reference ships (Resources/Sheen_E.exr) was decoded to tests/golden/sheen_e_16x16.npy by
+    tools/decode_sheen_lut.py; the C++ EXR reader must produce the same table (channel R) when the file is present."""
+    p = "/root/reference/Resources/Sheen_E.exr"
+    if not os.path.exists(p):
+        pytest.skip("reference tree not present (GPU box)")
+    with pytest.raises(MiptError, match="missing R, G or B"):          # the environment-map loader's rules reject a Y-only file
+        G.load_rgb32f(p)
+    got, half = G.decode_rgb32f(open(p, "rb").read(), 2)               # LoadLookupTables rules: one HALF channel (PIZ file whose only block is stored raw)
+    assert half
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "sheen_e_16x16.npy")).reshape(16, 16)
+    assert got.shape[:2] == (16, 16) and np.array_equal(got[..., 0], gold)

@@ -31,6 +31,13 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert hasattr(L, s), "libmipt.so does not export %s" % s
     assert sorted(renderer.EXPORTS) == syms
     assert L.pt_abi_version() == 1
+    # the scene side (include/mipt_scene.h): loader, animation, image readers
+    from gltf_renderer_amd import gltf
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mipt_scene.h")).read(), flags=re.S)
+    scene_syms = sorted(set(re.findall(r"\b((?:gs|img)_[a-z_0-9]+)\s*\(", text)))
+    assert len(scene_syms) >= 25 and sorted(gltf.SCENE_EXPORTS) == scene_syms
+    for s in scene_syms:
+        assert hasattr(L, s), "libmipt.so does not export %s" % s
 
 
 def test_product_fails_loudly_without_gpu():
