@@ -31,6 +31,7 @@ class SceneData:
         self.settings = PtSettings.app_defaults()
         self.bounce_limit = abi.REFERENCE_MAX_BOUNCES
         self.skins = []        # dynamic-mesh records (config 5)
+        self.mesh_records = [] # (Mesh, 4x4 transform, material_id) per instance
         self.triangles = 0
 
     # ---- building -------------------------------------------------------------------------------
@@ -77,6 +78,7 @@ class SceneData:
         d.num_of_indices = mesh.num_indices
         d.dynamic = 1 if dynamic else 0
         self.instances.append(d)
+        self.mesh_records.append((mesh, T, material_id))       # sources kept so a scene can be written out as glTF (tests/scene_export.py)
         self.triangles += mesh.num_indices // 3
         return len(self.instances) - 1
 

@@ -600,3 +600,66 @@ def test_sheen_lut_exr_of_the_reference_matches_the_committed_table():
     assert half
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "sheen_e_16x16.npy")).reshape(16, 16)
     assert got.shape[:2] == (16, 16) and np.array_equal(got[..., 0], gold)
+
+
+def test_exported_procedural_scene_round_trips_through_the_loader(tmp_path):
+    """scenes.test_scene -> GLB -> C++ loader: the loader must hand back the data model the scene was built from."""
+    from gltf_renderer_amd import scenes
+    from tests.scene_export import scene_to_builder
+    s = scenes.test_scene(64, 32)
+    sc = G.GltfScene(scene_to_builder(s).write_glb(str(tmp_path / "test_scene.glb")))
+    sc.calculate_global_transforms(0)
+    c = sc.counts()
+    assert c.materials == len(s.materials) and c.lights == len(s.lights) and c.textures == len(s.textures) and c.samplers == len(s.samplers)
+    order = []
+    def walk(n):
+        order.append(n)
+        k = sc.node(n).child
+        while k != -1:
+            walk(k); k = sc.node(k).sibling
+    for r in sc.scene_nodes(0):
+        walk(r)
+    mesh_nodes = [n for n in order if sc.node(n).mesh != -1]
+    assert len(mesh_nodes) == len(s.instances)
+    flat_of_mesh = {}
+    for f in range(c.primitives):
+        flat_of_mesh[sc.primitive(f)["mesh"]] = f
+    for n, d in zip(mesh_nodes, s.instances):
+        ni = sc.node(n)
+        assert np.allclose(np.array(ni.global_transform[:]), np.array(d.gpu.transform[:]), rtol=2e-6, atol=2e-6)
+        p = sc.primitive(flat_of_mesh[ni.mesh])
+        g = d.gpu
+        assert p["material_id"] == g.material_id and p["num_vertices"] == d.num_of_vertices
+        assert np.array_equal(p["position"].reshape(-1), s.buffers[g.position_descriptor][0].reshape(-1))
+        if g.index_descriptor != -1:
+            assert np.array_equal(p["index"], s.buffers[g.index_descriptor][0].reshape(-1))
+        else:
+            assert p["index"] is None
+        for k in range(2):
+            if g.texcoord_descriptors[k] != -1:
+                assert np.array_equal(p["texcoord%d" % k].reshape(-1), s.buffers[g.texcoord_descriptors[k]][0].reshape(-1))
+        if g.color_descriptor != -1:
+            assert np.abs(p["color"].astype(int).reshape(-1) - s.buffers[g.color_descriptor][0].astype(int).reshape(-1)).max() <= 1
+        if g.tangent_space_descriptor != -1:
+            assert ts_close(p["tangent_space"], s.buffers[g.tangent_space_descriptor][0].reshape(-1))
+    for i, m in enumerate(s.materials):
+        lm = sc.material(i)
+        for k in ("flags", "alpha_mode", "metalness_factor", "roughness_factor", "alpha_cutoff", "ior", "normal_scale", "specular_factor", "clearcoat_factor",
+                  "clearcoat_roughness_factor", "clearcoat_normal_scale", "anisotropy_strength", "anisotropy_rotation", "sheen_roughness_factor", "transmission_factor"):
+            assert getattr(lm, k) == getattr(m, k), (i, k)
+        for k in ("base_color_factor", "emissive_factor", "specular_color_factor", "sheen_color_factor"):
+            assert list(getattr(lm, k)[:]) == list(getattr(m, k)[:]), (i, k)
+        for k in SLOTS:
+            a, b_ = getattr(lm, k), getattr(m, k)
+            assert (a.descriptor, a.sampler, a.tex_coord, a.rotation, tuple(a.offset[:]), tuple(a.scale[:])) == \
+                   (b_.descriptor, b_.sampler, b_.tex_coord, b_.rotation, tuple(b_.offset[:]), tuple(b_.scale[:])), (i, k)
+    for i, (px, srgb) in enumerate(s.textures):
+        t = sc.texture(i)
+        assert t["loaded"] and t["srgb"] == srgb and np.array_equal(t["rgba"], px), i
+    for got, want in zip(sc.gather_lights(0), s.lights):
+        assert got.type == want.type and got.intensity == want.intensity and got.cutoff == want.cutoff
+        # GatherLights normalises the 4-vector inverseTranspose(global) * (0,0,-1,0) including its w (Renderer.cpp:483), so a
+        # translated light's direction is shorter than 1; the shader re-normalises (Lights.hlsli:28-61)
+        gd = np.array(got.direction[:], np.float64)
+        assert np.allclose(got.position[:], want.position[:], atol=1e-6) and np.allclose(gd / np.linalg.norm(gd), want.direction[:], atol=1e-6)
+        assert np.allclose(got.color[:], want.color[:]) and got.inner_angle == want.inner_angle and got.outer_angle == want.outer_angle
