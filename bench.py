@@ -5,8 +5,10 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 la
 torch.distributed.run, one rank per GPU.  A "step" = one pt_trace of the whole frame (1 sample per
 pixel, BASELINE.json metric) on the Sponza-class stand-in (configs[2]: 1920x1080, 8 bounces + RR,
 punctual lights + env MIS).  With N ranks the frame is sharded by 16x16 pixel tile (tile t -> rank
-t % N), every rank renders its tiles into a zeroed full-size image and ONE RCCL reduce(sum) to rank 0
-assembles the frame (tiles are disjoint, so sum = gather).  Total work is fixed -> "strong" scaling.
+t % N), every rank renders its tiles and ONE exchange per frame assembles the image on rank 0: by
+default each rank sends only its own tiles point to point over its direct xGMI link (--exchange gather),
+or an RCCL reduce(sum) of the zeroed full-size image (--exchange reduce); tiles are disjoint, so both
+give the same bits.  Total work is fixed -> "strong" scaling.
 
 Timed region: inputs (scene, BVH, textures, env maps) are resident in HBM; K steps bracketed by
 barrier + torch.cuda.synchronize on both sides; time = max over ranks.  value = rays traced by all
@@ -46,6 +48,7 @@ def main():
     ap.add_argument("--stage-blocks", type=int, default=0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --single-device rehearses N ranks on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (RCCL needs one device per rank)")
+    ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"], help="per-frame assembly on rank 0: own-tile gather (default) or full-image reduce")
     ap.add_argument("--animate", action="store_true", help="config 5 (--config figure): skin -> BVH rebuild -> trace every step, accumulation reset each frame")
     args = ap.parse_args()
 
@@ -71,7 +74,7 @@ def main():
 
     from gltf_renderer_amd import scenes, abi
     from gltf_renderer_amd.renderer import Renderer
-    from gltf_renderer_amd.sharding import reduce_frame
+    from gltf_renderer_amd.sharding import TileExchange, reduce_frame
 
     t_setup = time.time()
     if args.config == "sponza":
@@ -103,14 +106,28 @@ def main():
     accel_ms = r.stats().accel_ms
     t_setup = time.time() - t_setup
 
+    # The one exchange per frame (sharding.py): "gather" = every rank sends only its own tiles to rank 0 point to point over
+    # its direct xGMI link; "reduce" = RCCL reduce(sum) of the zeroed full-size image.  Both assemble the same bits.
+    exchange = {"mode": args.exchange if world > 1 else "none"}
+    xch = TileExchange(s.width, s.height, world, "cuda" if args.backend == "nccl" else "cpu") if world > 1 else None
+
     def reduce_image(img):
-        if args.backend == "gloo":          # rehearsal path: gloo reduces host tensors
+        if args.backend == "gloo":          # rehearsal path: gloo moves host tensors
             host = img.cpu()
-            reduce_frame(host, world)
+            if exchange["mode"] == "gather":
+                xch.gather_frame(host, rank)
+            else:
+                reduce_frame(host, world)
             if rank == 0:
                 img.copy_(host)
+        elif exchange["mode"] == "gather":
+            xch.gather_frame(img, rank)
         else:
             reduce_frame(img, world)        # one RCCL reduce(sum) of the accumulation buffer over xGMI
+
+    def clear_for_exchange():
+        if exchange["mode"] == "reduce":    # the sum needs zeros outside this rank's tiles; the gather does not read them
+            out.zero_()
 
     def animate(frame):
         if binding is not None:           # Main.cpp:521-523: a playing animation resets accumulation every frame
@@ -121,8 +138,8 @@ def main():
     def step(frame):
         animate(frame)
         if world > 1:
-            out.zero_()
-            settings.reset = 1          # each step is a fresh 1-spp frame when sharded (the reduce sums disjoint tiles)
+            clear_for_exchange()
+            settings.reset = 1          # each step is a fresh 1-spp frame when sharded (the exchange assembles disjoint tiles)
         p = s.execute_params(frame=frame, tile_rank=rank, tile_rank_count=world, env_handle=h["env"])
         r.trace(settings, p, out)
         if world > 1:
@@ -133,6 +150,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1 and exchange["mode"] == "gather":
+        try:                                  # probe once: a backend without gather falls back to the reduce on every rank alike
+            step(0)
+            torch.cuda.synchronize()
+        except Exception as e:               # noqa: BLE001
+            if rank == 0:
+                print("gather exchange unavailable (%s); using reduce" % e, file=sys.stderr)
+            exchange["mode"] = "reduce"
     for f in range(args.warmup):
         step(f)
     sync_all()
@@ -144,7 +169,7 @@ def main():
         frame = args.warmup + k
         animate(frame)
         if world > 1:
-            out.zero_()
+            clear_for_exchange()
             settings.reset = 1
         p = s.execute_params(frame=frame, tile_rank=rank, tile_rank_count=world, env_handle=h["env"])
         ev[k][0].record()
@@ -179,7 +204,8 @@ def main():
                        % (s.name, s.width, s.height, settings.max_bounces, s.bounce_limit, settings.min_bounces,
                           settings.min_russian_roulette_continue_prob, settings.max_russian_roulette_continue_prob, s.triangles,
                           len(s.instances), len(s.textures), len(s.lights), settings.flags),
-                       "parallelism": "tile-shard x%d + 1 RCCL reduce/frame" % world if world > 1 else "single GPU",
+                       "parallelism": ("tile-shard x%d + 1 RCCL %s/frame" % (world, "tile gather to rank 0 (point to point)" if exchange["mode"] == "gather" else "reduce(sum)"))
+                                      if world > 1 else "single GPU",
                        "rays_per_frame": round(rays_total / args.steps, 1), "bvh_build_ms": round(accel_ms, 3), "scene_setup_s": round(t_setup, 1)},
         }
 
