@@ -8,7 +8,20 @@ punctual lights + env MIS).  With N ranks the frame is sharded by 16x16 pixel ti
 t % N), every rank renders its tiles and ONE exchange per frame assembles the image on rank 0: by
 default each rank sends only its own tiles point to point over its direct xGMI link (--exchange gather),
 or an RCCL reduce(sum) of the zeroed full-size image (--exchange reduce); tiles are disjoint, so both
-give the same bits.  Total work is fixed -> "strong" scaling.
+give the same bits.
+
+Samples per step.  One pt_trace carries a SAMPLE BATCH (pt_set_samples_per_trace): S samples per pixel in
+one set of kernel launches, bit-identical to S consecutive reference frames (tested).  An offline path
+tracer accumulates hundreds of samples, and a batch keeps 256 CUs full through the thin late bounces:
+1080p on one MI355X goes from 2.56 Grays/s at S = 1 to 3.29 at S = 8 (3.48 at 32).  Default S = 8 per GPU;
+`config.ms_per_1spp_frame` is the step time / S and `config.ms_single_sample_launch` the latency of an
+S = 1 launch, measured beside it.
+
+Scaling (N > 1).  Default "weak": a step accumulates 8 x N samples per pixel of the tile-sharded frame, so
+every rank keeps the work of a 1-GPU step (1/N of the tiles x 8N samples) in ONE batch - a 1/N tile shard
+of a single sample cannot fill a 256-CU GPU (measured: 0.99 Grays/s per GPU at N = 8), a batch can (2.5) -
+then one exchange of the accumulated tiles.  `--scaling strong` keeps 8 samples per pixel per step split N
+ways (total work fixed).  The JSON line says which.
 
 Timed region: inputs (scene, BVH, textures, env maps) are resident in HBM; K steps bracketed by
 barrier + torch.cuda.synchronize on both sides; time = max over ranks.  value = rays traced by all
@@ -48,6 +61,11 @@ def main():
     ap.add_argument("--stage-blocks", type=int, default=0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --single-device rehearses N ranks on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (RCCL needs one device per rank)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every step accumulates N samples per pixel of the tile-sharded frame in one sample batch (per-GPU work fixed); "
+                         "strong = every step is one sample per pixel split N ways (total work fixed)")
+    ap.add_argument("--spp", type=int, default=0,
+                    help="samples per pixel per step (sample batch, pt_set_samples_per_trace); default 8 on one GPU, 8 x N with --scaling weak (max 64)")
     ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"], help="per-frame assembly on rank 0: own-tile gather (default) or full-image reduce")
     ap.add_argument("--animate", action="store_true", help="config 5 (--config figure): skin -> BVH rebuild -> trace every step, accumulation reset each frame")
     args = ap.parse_args()
@@ -101,6 +119,11 @@ def main():
         binding.pose(0.0)
     r.build_accel()
     settings = s.settings
+    SPP_PER_GPU = 8                           # an offline renderer accumulates many samples: 8 per launch amortise the stage tails
+    spp = args.spp if args.spp > 0 else min(SPP_PER_GPU * (world if args.scaling == "weak" else 1), 64)
+    if args.animate:
+        spp = 1                               # a playing animation resets accumulation every frame (Main.cpp:521-523)
+    r.set_samples_per_trace(spp)              # one launch carries the step's samples: a 1/N tile shard still fills the GPU
     out = r.create_output(s.width, s.height)
     torch.cuda.synchronize()
     accel_ms = r.stats().accel_ms
@@ -140,7 +163,7 @@ def main():
         if world > 1:
             clear_for_exchange()
             settings.reset = 1          # each step is a fresh 1-spp frame when sharded (the exchange assembles disjoint tiles)
-        p = s.execute_params(frame=frame, tile_rank=rank, tile_rank_count=world, env_handle=h["env"])
+        p = s.execute_params(frame=frame * spp, tile_rank=rank, tile_rank_count=world, env_handle=h["env"])
         r.trace(settings, p, out)
         if world > 1:
             reduce_image(out)
@@ -171,7 +194,7 @@ def main():
         if world > 1:
             clear_for_exchange()
             settings.reset = 1
-        p = s.execute_params(frame=frame, tile_rank=rank, tile_rank_count=world, env_handle=h["env"])
+        p = s.execute_params(frame=frame * spp, tile_rank=rank, tile_rank_count=world, env_handle=h["env"])
         ev[k][0].record()
         r.trace(settings, p, out)
         ev[k][1].record()
@@ -198,23 +221,39 @@ def main():
         result = {
             "metric": "Mrays/sec + ms/frame @1920x1080, 8-bounce, 1/2/4/8 MI355X",
             "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1000.0, 4), "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": round(elapsed / args.steps * 1000.0, 4), "higher_is_better": True,
+            "scaling": "weak" if (args.scaling == "weak" and args.spp <= 0) else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s %dx%d 1spp/step, max_bounces %d (limit %d), min_bounces %d, RR %.1f-%.1f, %d triangles / %d instances / %d textures / %d lights, env-map MIS, flags 0x%x"
-                       % (s.name, s.width, s.height, settings.max_bounces, s.bounce_limit, settings.min_bounces,
+            "config": {"workload": "%s %dx%d %dspp/step, max_bounces %d (limit %d), min_bounces %d, RR %.1f-%.1f, %d triangles / %d instances / %d textures / %d lights, env-map MIS, flags 0x%x"
+                       % (s.name, s.width, s.height, spp, settings.max_bounces, s.bounce_limit, settings.min_bounces,
                           settings.min_russian_roulette_continue_prob, settings.max_russian_roulette_continue_prob, s.triangles,
                           len(s.instances), len(s.textures), len(s.lights), settings.flags),
                        "parallelism": ("tile-shard x%d + 1 RCCL %s/frame" % (world, "tile gather to rank 0 (point to point)" if exchange["mode"] == "gather" else "reduce(sum)"))
                                       if world > 1 else "single GPU",
-                       "rays_per_frame": round(rays_total / args.steps, 1), "bvh_build_ms": round(accel_ms, 3), "scene_setup_s": round(t_setup, 1)},
+                       "samples_per_step": spp, "ms_per_1spp_frame": round(elapsed / args.steps / spp * 1000.0, 4),
+                       "rays_per_frame": round(rays_total / args.steps / spp, 1), "bvh_build_ms": round(accel_ms, 3), "scene_setup_s": round(t_setup, 1)},
         }
+
+    # ---- latency of a single-sample launch (one reference frame), untimed, beside the batched throughput
+    if rank == 0 and world == 1 and spp > 1 and binding is None:
+        r.set_samples_per_trace(1)
+        lat = []
+        for k in range(6):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            r.trace(settings, s.execute_params(frame=100000 + k, env_handle=h["env"]), out)
+            b.record()
+            torch.cuda.synchronize()
+            lat.append(a.elapsed_time(b))
+        result["config"]["ms_single_sample_launch"] = round(sorted(lat[1:])[len(lat[1:]) // 2], 4)
+        r.set_samples_per_trace(spp)
 
     # ---- config 5: skin / BVH rebuild / trace split, measured on an untimed synchronised replay of a few frames
     if rank == 0 and binding is not None:
         parts = {"skin_ms": [], "accel_ms": [], "trace_ms": []}
         for k in range(min(args.steps, 8)):
             animate(args.warmup + k)
-            r.trace(settings, s.execute_params(frame=args.warmup + k, tile_rank=rank, tile_rank_count=world, env_handle=h["env"]), out)
+            r.trace(settings, s.execute_params(frame=(args.warmup + k) * spp, tile_rank=rank, tile_rank_count=world, env_handle=h["env"]), out)
             torch.cuda.synchronize()
             st2 = r.stats()
             parts["skin_ms"].append(st2.skin_ms); parts["accel_ms"].append(st2.accel_ms); parts["trace_ms"].append(st2.trace_ms)
@@ -232,7 +271,7 @@ def main():
             animate(args.warmup + k)
             if binding is not None:
                 settings2.reset = 1
-            p = s.execute_params(frame=args.warmup + k, env_handle=h["env"])
+            p = s.execute_params(frame=(args.warmup + k) * spp, env_handle=h["env"])
             r.trace(settings2, p, out2)
         c = r.stats()
         r.enable_counters(False)
@@ -242,7 +281,7 @@ def main():
         # 128 B (the 4-wide node this build uses; the survey's 64 B assumed binary nodes).
         s_hit = 12 + 3 * (12 + 4 + 8) + 176 + 640            # indices + 3 vertices + instance row + material
         alg = (c.nodes_visited * 128 + c.tris_tested * 48 + c.closest_hits * s_hit + c.texture_taps * 16
-               + (c.closest_hits * 40 * 4 if env_mis else 0) + (c.rays_primary + c.rays_bounce - c.closest_hits) * 64) / n + s.width * s.height * 32
+               + (c.closest_hits * 40 * 4 if env_mis else 0) + (c.rays_primary + c.rays_bounce - c.closest_hits) * 64) / n + s.width * s.height * 32 * spp
         mean_ms = sum(kernel_ms) / len(kernel_ms)
         achieved = alg / (mean_ms * 1e-3) / 1e9
         traffic = None

@@ -59,6 +59,7 @@ struct pt_ctx {
     hipEvent_t ev_trace[2] = {nullptr, nullptr}, ev_accel[2] = {nullptr, nullptr}, ev_skin[2] = {nullptr, nullptr};
     bool have_trace = false, have_accel = false, have_skin = false;
     int bounce_limit = PT_REFERENCE_MAX_BOUNCES;
+    int samples_per_trace = 1;
     bool counters_enabled = false;
 
     // ---- Pathtracer cross-frame state (Source/Pathtracer.h:152-153)
@@ -231,11 +232,30 @@ public:
             uint32_t ntiles = fc.tiles_x * fc.tiles_y;
             fc.my_tiles = ntiles > fc.tile_rank ? (ntiles - fc.tile_rank + fc.tile_rank_count - 1) / fc.tile_rank_count : 0;
 
+            // Sample batch (pt_set_samples_per_trace): this call stands for `batch` consecutive PathtraceScene calls of frames
+            // frame .. frame + batch - 1 with an unchanged camera.  Only accumulation makes more than the last one observable,
+            // and the batch may not run past max_accumulated_frames (the calls beyond it would have been no-ops, :273).
+            int batch = 1;
+            if ((settings->flags & PT_FLAG_ACCUMULATE) && settings->debug_output == PT_DEBUG_OUTPUT_NONE) {
+                batch = ctx->samples_per_trace;
+                const long long room = (long long)settings->max_accumulated_frames - ctx->accumulated_frames;
+                if ((long long)batch > room) batch = (int)room;
+            }
+            fc.spp = 1; fc.pixel_slots = fc.my_tiles * 256u;
+            fc.seed_step = settings->use_frame_as_seed ? 1u : 0u;
+
             HIPOK(hipEventRecord(ctx->ev_trace[0], ctx->stream));
             if (ctx->kernel_mode == PT_MODE_MEGAKERNEL) {
-                launch_megakernel(sc, fc, (float4*)ep->output, ctx->d_counters, ctx->counters_enabled, ctx->stream);   // :344-353
+                for (int k = 0; k < batch; k++) {                                        // the megakernel has no batch form: one launch per sample
+                    FrameConstants fk = fc;
+                    fk.seed = fc.seed + (uint32_t)k * fc.seed_step;
+                    fk.accumulated_frames = fc.accumulated_frames + k;
+                    launch_megakernel(sc, fk, (float4*)ep->output, ctx->d_counters, ctx->counters_enabled, ctx->stream);   // :344-353
+                }
             } else {
-                size_t need = wavefront_workspace_bytes(fc.my_tiles * 256u, ctx->stage_blocks);
+                fc.spp = (uint32_t)batch;
+                if ((unsigned long long)fc.pixel_slots * fc.spp > 0x7fffffffull) return ctx->fail(PT_ERR_CAPACITY, "sample batch too large for this resolution");
+                size_t need = wavefront_workspace_bytes(fc.pixel_slots * fc.spp, ctx->stage_blocks);
                 if (need > ctx->workspace_cap) {
                     HIPOK(hipStreamSynchronize(ctx->stream));
                     hipFree(ctx->d_workspace); ctx->d_workspace = nullptr; ctx->workspace_cap = 0;
@@ -247,7 +267,7 @@ public:
             HIPOK(hipGetLastError());
             HIPOK(hipEventRecord(ctx->ev_trace[1], ctx->stream));
             ctx->have_trace = true;
-            if (settings->flags & PT_FLAG_ACCUMULATE) ctx->accumulated_frames++;          // :355-359
+            if (settings->flags & PT_FLAG_ACCUMULATE) ctx->accumulated_frames += batch;   // :355-359
             else ctx->accumulated_frames = 0;
         }
         memcpy(ctx->previous_world_to_clip, world_to_clip, 64);                          // :366
@@ -599,6 +619,12 @@ int pt_trace(pt_ctx* ctx, const pt_settings* settings, const pt_execute_params* 
 int pt_set_bounce_limit(pt_ctx* ctx, int limit) {
     if (!ctx || limit < 0) return PT_ERR_INVALID_ARGUMENT;
     ctx->bounce_limit = limit;
+    return PT_OK;
+}
+
+int pt_set_samples_per_trace(pt_ctx* ctx, int samples) {
+    if (!ctx || samples < 1 || samples > PT_MAX_SAMPLES_PER_TRACE) return PT_ERR_INVALID_ARGUMENT;
+    ctx->samples_per_trace = samples;
     return PT_OK;
 }
 

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(SceneRec sc, FrameConsta
     fu.q_env = fu.q_light = fu.q_bounce = false;
     fu.pend_env = fu.pend_light = v3(0);
     if (alive) {
-        ray = camera_ray(fc, px, py, ps.rc);
+        ray = camera_ray(fc, fc.seed, px, py, ps.rc);
         rf = (flags & PT_FLAG_CULL_BACKFACE) ? RF_CULL_BACK : 0;
         n_primary++;
     }
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(SceneRec sc, FrameConsta
         else if (!got) { L += shade_miss(sc, fc, ray.d, ps); alive = false; }
         else {
             n_hits++;
-            bool done = shade_closest_hit(sc, fc, px, py, ray, hit, ps, fu, st.taps);
+            bool done = shade_closest_hit(sc, fc, fc.seed, px, py, ray, hit, ps, fu, st.taps);
             if (fu.overwrite) L = v3(0);
             L += fu.add;
             n_shadow += fu.counted_shadow;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(SceneRec sc, FrameConsta
             } else alive = false;
         }
     }
-    if (in_image) write_pixel(fc, output, px, py, L);
+    if (in_image) write_pixel(fc, fc.accumulated_frames, output, px, py, L);
     flush_counters(counters, threadIdx.x & 63, n_primary, n_bounce, n_shadow, n_hits, st);
 }
 

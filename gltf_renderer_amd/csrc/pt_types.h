@@ -143,6 +143,9 @@ struct FrameConstants {
     uint32_t tiles_x, tiles_y;       // 16x16 tiles
     uint32_t tile_rank, tile_rank_count;
     uint32_t my_tiles;               // tiles this rank renders
+    // Sample batch: one launch carries `spp` samples of every pixel (slot = sample * pixel_slots + pixel slot), equivalent to
+    // `spp` consecutive PathtraceScene calls: sample k uses seed + k * seed_step and blends with accumulated_frames + k.
+    uint32_t spp, pixel_slots, seed_step;
 };
 
 struct Counters {

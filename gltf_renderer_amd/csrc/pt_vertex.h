@@ -42,7 +42,7 @@ PT_DEV vec3 shade_miss(const SceneRec& sc, const FrameConstants& fc, vec3 dir, c
 }
 
 // Returns true when the path ends at this vertex for a debug output (fu.add holds beta * debug colour).
-PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint32_t px, uint32_t py, const Ray& ray, const HitRec& hit,
+PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint32_t seed, uint32_t px, uint32_t py, const Ray& ray, const HitRec& hit,
                               PathState& ps, Followups& fu, unsigned& taps) {
     const uint32_t flags = fc.flags;
     fu.add = v3(0); fu.overwrite = false; fu.counted_shadow = 0;
@@ -103,7 +103,7 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
     fu.origin_above = o_above;
     // environment NEE :929-942 (SampleEnvironmentMap :688-703)
     if (ps.bounce < fc.max_bounces && (flags & PT_FLAG_ENVIRONMENT_MAP) && (flags & PT_FLAG_ENVIRONMENT_MIS)) {
-        vec4 r = next_random(px, py, fc.seed, ps.rc);
+        vec4 r = next_random(px, py, seed, ps.rc);
         float light_pdf = 1;
         vec3 ldir = v3(0, 0, 1), lcol = v3(0);
         if (sc.has_env) {
@@ -124,7 +124,7 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
     }
     // punctual-light NEE :945-956 (SamplePointLight :680-686)
     if ((flags & PT_FLAG_POINT_LIGHTS) && fc.num_of_lights > 0) {
-        float u = next_random(px, py, fc.seed, ps.rc).x;
+        float u = next_random(px, py, seed, ps.rc).x;
         uint32_t li = f2u(u * (float)fc.num_of_lights);
         li = min(li, (uint32_t)(fc.num_of_lights - 1));                                              // u may be exactly 1 (quirk q17)
         float pdf = 1.0f / (float)fc.num_of_lights;
@@ -142,7 +142,7 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
     fu.add = ps.beta * c;
     // BSDF sampling + Russian roulette :958-1006
     if (ps.bounce < fc.max_bounces) {
-        vec4 r = next_random(px, py, fc.seed, ps.rc);
+        vec4 r = next_random(px, py, seed, ps.rc);
         bool is_tr = false, use_mis = false;
         float bp = 1;
         vec3 l = v3(0);
@@ -167,7 +167,7 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
             return true;
         }
         if (any_gt0(throughput)) {
-            float ur = next_random(px, py, fc.seed, ps.rc).x;                                        // drawn even below min_bounces (quirk q6)
+            float ur = next_random(px, py, seed, ps.rc).x;                                        // drawn even below min_bounces (quirk q6)
             bool cont = ps.bounce < fc.min_bounces;
             if (!cont) {                                                                             // RussianRoulette :712-722
                 float p = clampf(max3(throughput), fc.min_rr, fc.max_rr);
@@ -187,8 +187,8 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
 }
 
 // RayGeneration prologue :744-758 (GenerateCameraRay :131-142)
-PT_DEV Ray camera_ray(const FrameConstants& fc, uint32_t px, uint32_t py, int& rc) {
-    vec4 r = next_random(px, py, fc.seed, rc);
+PT_DEV Ray camera_ray(const FrameConstants& fc, uint32_t seed, uint32_t px, uint32_t py, int& rc) {
+    vec4 r = next_random(px, py, seed, rc);
     float jx = r.x - 0.5f, jy = r.y - 0.5f;
     float cx = (((float)px + 0.5f + jx) / (float)fc.res_x) * 2 - 1;
     float cy = (((float)py + 0.5f + jy) / (float)fc.res_y) * 2 - 1;
@@ -203,7 +203,8 @@ PT_DEV Ray camera_ray(const FrameConstants& fc, uint32_t px, uint32_t py, int& r
 }
 
 // RayGeneration epilogue :760-785
-PT_DEV void write_pixel(const FrameConstants& fc, float4* __restrict__ output, uint32_t px, uint32_t py, vec3 L) {
+// `accumulated` = frames already in the output when this sample is blended (SceneConstants.accumulated_frames).
+PT_DEV void write_pixel(const FrameConstants& fc, int accumulated, float4* __restrict__ output, uint32_t px, uint32_t py, vec3 L) {
     const uint32_t flags = fc.flags;
     if (any_nan(L)) L = (flags & PT_FLAG_SHOW_NAN) ? v3(1, 0, 0) : v3(0);
     if (any_inf(L)) L = (flags & PT_FLAG_SHOW_INF) ? v3(1, 0, 0) : v3(0);
@@ -212,15 +213,19 @@ PT_DEV void write_pixel(const FrameConstants& fc, float4* __restrict__ output, u
         if (lum > fc.luminance_clamp) L *= fc.luminance_clamp / lum;
     }
     float4* outp = output + ((size_t)py * fc.res_x + px);
-    if ((flags & PT_FLAG_ACCUMULATE) && fc.accumulated_frames != 0) {
+    if ((flags & PT_FLAG_ACCUMULATE) && accumulated != 0) {
         float4 h = *outp;
-        float blend = 1.0f / ((float)fc.accumulated_frames + 1.0f);
+        float blend = 1.0f / ((float)accumulated + 1.0f);
         *outp = make_float4(h.x + blend * (L.x - h.x), h.y + blend * (L.y - h.y), h.z + blend * (L.z - h.z), h.w + blend * (1.0f - h.w));
     } else *outp = make_float4(L.x, L.y, L.z, 1.0f);
 }
 
 // tile-sharded pixel of a (rank-local) slot: slot -> (tile of this rank, lane in tile), one wave64 per 8x8 quadrant
+// sample index of a slot in a sample batch (0 when spp == 1), and the seed that sample draws with
+PT_DEV uint32_t slot_sample(const FrameConstants& fc, uint32_t slot) { return fc.spp > 1 ? slot / fc.pixel_slots : 0u; }
+PT_DEV uint32_t sample_seed(const FrameConstants& fc, uint32_t sample) { return fc.seed + sample * fc.seed_step; }
 PT_DEV bool slot_pixel(const FrameConstants& fc, uint32_t slot, uint32_t& px, uint32_t& py) {
+    if (fc.spp > 1) slot -= (slot / fc.pixel_slots) * fc.pixel_slots;
     const uint32_t local_tile = slot >> 8, t = slot & 255;
     const uint32_t tile = fc.tile_rank + local_tile * fc.tile_rank_count;
     const uint32_t tx = tile % fc.tiles_x, ty = tile / fc.tiles_x;

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_generate(FrameConstants fc, WfBuf
         int rc = 0;
         Ray ray;
         ray.o = v3(0); ray.d = v3(0, 0, 1); ray.tmin = 0; ray.tmax = 0;
-        if (valid) ray = camera_ray(fc, px, py, rc);
+        if (valid) ray = camera_ray(fc, sample_seed(fc, slot_sample(fc, slot)), px, py, rc);
         const uint32_t idx = queue_push(wf.cnt[0] + sv.shard * kCounterStride, valid);
         if (valid) {
             const size_t e = (size_t)sv.shard * wf.seg_cap + idx;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
                 uint32_t px, py;
                 slot_pixel(fc, slot, px, py);
                 n_hits++;
-                const bool done = shade_closest_hit(sc, fc, px, py, ray, hit, ps, fu, st.taps);
+                const bool done = shade_closest_hit(sc, fc, sample_seed(fc, slot_sample(fc, slot)), px, py, ray, hit, ps, fu, st.taps);
                 if (fu.overwrite) L = v3(0);
                 L += fu.add;
                 n_shadow += fu.counted_shadow;
@@ -306,13 +306,17 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_shadow(SceneRec s
 }
 
 __global__ __launch_bounds__(kBlock) void k_wf_resolve(FrameConstants fc, WfBuffers wf, float4* __restrict__ output) {
-    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t pslot = blockIdx.x * kBlock + threadIdx.x;       // pixel slot; its samples sit pixel_slots apart
     uint32_t px, py;
-    if (slot >= wf.capacity || !slot_pixel(fc, slot, px, py)) return;
-    float4 Lq = wf.L[slot];
-    vec3 L = v3(Lq.x, Lq.y, Lq.z);
-    apply_pending(wf, slot, L);
-    write_pixel(fc, output, px, py, L);
+    if (pslot >= fc.pixel_slots || !slot_pixel(fc, pslot, px, py)) return;
+    // the samples of a batch are blended in sample order, exactly as consecutive PathtraceScene calls would (running mean)
+    for (uint32_t k = 0; k < fc.spp; k++) {
+        const uint32_t slot = k * fc.pixel_slots + pslot;
+        float4 Lq = wf.L[slot];
+        vec3 L = v3(Lq.x, Lq.y, Lq.z);
+        apply_pending(wf, slot, L);
+        write_pixel(fc, fc.accumulated_frames + (int)k, output, px, py, L);
+    }
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
@@ -358,7 +362,7 @@ static WfBuffers carve(void* base, uint32_t slots, int stage_blocks) {
 hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4* output, Counters* counters, bool count, void* workspace,
                             int stage_blocks, hipStream_t stream) {
     if (fc.my_tiles == 0) return hipSuccess;
-    const uint32_t slots = fc.my_tiles * kBlock;
+    const uint32_t slots = fc.my_tiles * kBlock * fc.spp;
     WfBuffers wf = carve(workspace, slots, stage_blocks);
     hipError_t e = hipMemsetAsync(wf.cnt[0], 0, (size_t)5 * kShards * kCounterStride * 4, stream);     // the five counter arrays are contiguous
     if (e) return e;

@@ -362,6 +362,14 @@ int pt_skin_run(pt_ctx* ctx, const pt_skin_params* params, const pt_bone* bones,
  * accumulation resets when world_to_clip changes or settings->reset. */
 int pt_trace(pt_ctx* ctx, const pt_settings* settings, const pt_execute_params* params);
 int pt_set_bounce_limit(pt_ctx* ctx, int limit);      /* default PT_REFERENCE_MAX_BOUNCES */
+/* Sample batch: with samples > 1 one pt_trace stands for `samples` consecutive PathtraceScene calls (frames frame ..
+ * frame + samples - 1, camera unchanged) carried by ONE set of kernel launches, so a small image or a small tile shard
+ * still fills the GPU.  The output is bit-identical to issuing the calls one by one: sample k draws with the seed of frame
+ * frame + k (or settings->seed when use_frame_as_seed is 0) and is blended with weight 1 / (accumulated_frames + k + 1)
+ * in order; accumulated_frames advances by the batch and never passes max_accumulated_frames.  Without FLAG_ACCUMULATE,
+ * or with a debug output, the batch is ignored: the call renders the one sample of `frame`, as always.  Default 1. */
+#define PT_MAX_SAMPLES_PER_TRACE 64
+int pt_set_samples_per_trace(pt_ctx* ctx, int samples);
 int pt_enable_counters(pt_ctx* ctx, int enable);      /* node / triangle / tap counters (slower) */
 /* Kernel arrangement (same per-vertex code, same results up to fp32 accumulation order): PT_MODE_WAVEFRONT (default) =
  * staged trace / shade / shadow kernels over SoA ray queues in HBM with ballot compaction; PT_MODE_MEGAKERNEL = one

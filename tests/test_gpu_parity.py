@@ -215,6 +215,51 @@ def test_accumulation_semantics_on_gpu(R):
     r.close()
 
 
+@pytest.mark.parametrize("mode", [abi.MODE_WAVEFRONT, abi.MODE_MEGAKERNEL])
+def test_sample_batch_equals_the_same_frames_one_by_one(R, mode):
+    """pt_set_samples_per_trace: one launch carrying S samples must leave exactly the bits S consecutive calls leave --
+    per-sample seeds (frame + k), blend order, accumulated_frames, the max_accumulated_frames cap, tile shards."""
+    s = scenes.test_scene(72, 16)           # 4.5 tiles: ragged edge
+    r = R(); h = s.upload(r)
+    r.set_kernel_mode(mode)
+    for use_frame, shard in ((1, (0, 1)), (0, (0, 1)), (1, (1, 3))):
+        st = copy_settings(s.settings); st.use_frame_as_seed = use_frame; st.seed = 99; st.reset = 1
+        kw = dict(env_handle=h["env"], tile_rank=shard[0], tile_rank_count=shard[1])
+        one = r.create_output(s.width, s.height); many = r.create_output(s.width, s.height)
+        r.set_samples_per_trace(1)
+        for f in range(10, 17):                                     # 7 frames, one call each
+            r.trace(st, s.execute_params(f, **kw), one); st.reset = 0
+        rays_one = None
+        r.reset_stats()
+        st.reset = 1
+        r.set_samples_per_trace(4)
+        r.trace(st, s.execute_params(10, **kw), many); st.reset = 0  # frames 10..13
+        assert r.stats().accumulated_frames == 4
+        r.set_samples_per_trace(3)
+        r.trace(st, s.execute_params(14, **kw), many)               # frames 14..16
+        assert r.stats().accumulated_frames == 7
+        assert np.array_equal(r.readback(one), r.readback(many)), (use_frame, shard)
+    # the batch stops at max_accumulated_frames (the calls beyond it would have been no-ops, Pathtracer.cpp:273)
+    st = copy_settings(s.settings); st.max_accumulated_frames = 5; st.reset = 1
+    a = r.create_output(s.width, s.height); b = r.create_output(s.width, s.height)
+    r.set_samples_per_trace(1)
+    for f in range(5):
+        r.trace(st, s.execute_params(f, env_handle=h["env"]), a); st.reset = 0
+    st.reset = 1
+    r.set_samples_per_trace(8)
+    r.trace(st, s.execute_params(0, env_handle=h["env"]), b)
+    assert r.stats().accumulated_frames == 5 and np.array_equal(r.readback(a), r.readback(b))
+    # without accumulation the batch is ignored
+    st = copy_settings(s.settings); st.flags &= ~abi.FLAG_ACCUMULATE
+    r.set_samples_per_trace(1); r.trace(st, s.execute_params(3, env_handle=h["env"]), a)
+    r.set_samples_per_trace(4); r.reset_stats(); r.trace(st, s.execute_params(3, env_handle=h["env"]), b)
+    assert np.array_equal(r.readback(a), r.readback(b))
+    from gltf_renderer_amd.renderer import MiptError
+    with pytest.raises(MiptError):
+        r.set_samples_per_trace(0)
+    r.close()
+
+
 def test_tile_shards_compose_bit_exactly_on_gpu(R):
     s = scenes.test_scene(200, 16)          # 200 = 12.5 tiles: ragged edges
     r = R(); h = s.upload(r)
