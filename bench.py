@@ -28,7 +28,7 @@ barrier + torch.cuda.synchronize on both sides; time = max over ranks.  value = 
 ranks in the K steps / that time.  Rays are counted by the kernel itself (every traversal started).
 
 Extra objects on the JSON line:
-  roofline     - the wavefront pipeline of one pt_trace (one launch = one frame): algorithmic bytes per
+  roofline     - the wavefront pipeline of one pt_trace (one launch = one step = S samples): algorithmic bytes per
                  launch (counted by an untimed instrumented replay of the same K frames: nodes*128 +
                  tris*48 + hits*S_hit + taps*16 + env loads + 32 B/pixel) / mean per-frame kernel time
                  measured live with HIP events on the launch stream; peak = 8 TB/s HBM; traffic =
@@ -235,7 +235,7 @@ def main():
         }
 
     # ---- latency of a single-sample launch (one reference frame), untimed, beside the batched throughput
-    if rank == 0 and world == 1 and spp > 1 and binding is None:
+    if rank == 0 and world == 1 and spp > 1 and binding is None and not args.no_roofline:     # (--no-roofline = profiling runs: timed launches only)
         r.set_samples_per_trace(1)
         lat = []
         for k in range(6):
@@ -288,11 +288,14 @@ def main():
         pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pj) and args.config == "sponza" and not (args.width or args.height or args.animate) and args.mode == "wavefront":
             try:
-                traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
+                pm = json.load(open(pj))
+                if pm.get("samples_per_launch", 1) == spp:         # the PMC passes were taken at this batch size
+                    traffic = pm.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         kname = ("pt_megakernel" if args.mode == "megakernel" else
-                 "pt_trace wavefront pipeline (k_wf_generate + (k_wf_trace, k_wf_shade, k_wf_shadow) x (max_bounces+1) + k_wf_resolve; one launch = one frame)")
+                 "pt_trace wavefront pipeline (k_wf_generate + (k_wf_trace, k_wf_shade, k_wf_shadow) x (max_bounces+1) + k_wf_resolve; "
+                 "one launch = one pt_trace = %d sample(s) per pixel)" % spp)
         result["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                               "frac": round(achieved / 8000.0, 5), "traffic": traffic,
                               "algorithmic_bytes_per_launch": round(alg), "kernel_ms_mean": round(mean_ms, 4),
