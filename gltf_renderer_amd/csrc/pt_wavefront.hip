@@ -157,7 +157,7 @@ PT_DEV void trace_persistent(const SceneRec& sc, const WfBuffers& wf, int* my_st
         }
         // ---- node phase: every lane that holds an inner node steps until none does
 #ifndef PT_NODE_MIN
-#define PT_NODE_MIN 8         // leave the node phase early when fewer lanes than this hold an inner node AND some lane waits at a leaf
+#define PT_NODE_MIN 16        // (swept 4..32 at 8 samples per launch: 16) leave the node phase early when fewer lanes than this hold an inner node AND some lane waits at a leaf
                               // (swept 1/4/8/12/16/32 on MI355X: 2195/2326/2359/2360/2356/2294 Mrays/s)
 #endif
         for (;;) {
