@@ -1,8 +1,11 @@
 // pt_types.h -- device-side scene layout in HBM for the path-tracing kernels.
 //
 // Host PODs come from include/mipt.h (byte-identical to the reference's GPU structs).  What the
-// reference reaches through bindless descriptor indices (ResourceDescriptorHeap[i]) is reached here
-// through three small tables of raw device pointers: buffers, textures, samplers.
+// reference reaches through bindless descriptor indices (ResourceDescriptorHeap[i]) is resolved on the
+// host when a scene is set: instance rows carry their stream pointers (InstanceRec) and materials become
+// RMat records with texel pointers, packed sampler state and pre-multiplied UV transforms.  The
+// buffer / texture / sampler tables (BufferRec, TextureRec, SamplerRec) live on the host; only the buffer
+// table is also copied to the device, for the BVH build.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
