@@ -73,7 +73,11 @@ PT_DEV void trav_init(Trav& t, const SceneRec& sc, const Ray& r, uint32_t rf, ui
     t.cur = (mask == 0 || sc.num_tris == 0) ? kTravDone : sc.root;
 }
 
+// FAST: the caller has established (wave-uniformly) that no active lane can leave the LDS part of the stack in this step, so
+// a push is one predicated ds_write instead of a three-way LDS / scratch / overflow branch nest.
+template <bool FAST = false>
 PT_DEV void trav_push(Trav& t, int* lds_stack, int* spill, int ref, LaneStats& st) {
+    if (FAST) { lds_stack[t.sp * kBlock] = ref; t.sp++; return; }
     if (t.sp < kStackLds) lds_stack[t.sp * kBlock] = ref;
     else if (t.sp < kStackLds + kStackSpill) spill[t.sp - kStackLds] = ref;
     else st.overflow++;
@@ -113,13 +117,18 @@ PT_DEV void trav_node_step(Trav& t, const SceneRec& sc, int* lds_stack, int* spi
     PT_SLAB(2, c2, lox.z, loy.z, loz.z, hix.z, hiy.z, hiz.z)
     PT_SLAB(3, c3, lox.w, loy.w, loz.w, hix.w, hiy.w, hiz.w)
 #undef PT_SLAB
+    // a step pushes at most three entries: if no active lane is within three of the LDS part's end, every push is a plain ds_write
+    const bool shallow = __ballot(t.sp + 3 > kStackLds) == 0;
     if (!ORDERED) {
         // occlusion rays accept any hit: visiting order is irrelevant, skip the sort
         int next = kTravDone;
         if (key[0] != 0xffffffffu) next = c0;
-        if (key[1] != 0xffffffffu) { if (next != kTravDone) trav_push(t, lds_stack, spill, c1, st); else next = c1; }
-        if (key[2] != 0xffffffffu) { if (next != kTravDone) trav_push(t, lds_stack, spill, c2, st); else next = c2; }
-        if (key[3] != 0xffffffffu) { if (next != kTravDone) trav_push(t, lds_stack, spill, c3, st); else next = c3; }
+#define PT_PUSH_UNORDERED(F)                                                                                                        \
+        if (key[1] != 0xffffffffu) { if (next != kTravDone) trav_push<F>(t, lds_stack, spill, c1, st); else next = c1; }           \
+        if (key[2] != 0xffffffffu) { if (next != kTravDone) trav_push<F>(t, lds_stack, spill, c2, st); else next = c2; }           \
+        if (key[3] != 0xffffffffu) { if (next != kTravDone) trav_push<F>(t, lds_stack, spill, c3, st); else next = c3; }
+        if (shallow) { PT_PUSH_UNORDERED(true) } else { PT_PUSH_UNORDERED(false) }
+#undef PT_PUSH_UNORDERED
         if (next != kTravDone) t.cur = next; else trav_pop(t, lds_stack, spill);
         return;
     }
@@ -127,9 +136,12 @@ PT_DEV void trav_node_step(Trav& t, const SceneRec& sc, int* lds_stack, int* spi
     PT_CSWAP(key[0], key[1]) PT_CSWAP(key[2], key[3]) PT_CSWAP(key[0], key[2]) PT_CSWAP(key[1], key[3]) PT_CSWAP(key[1], key[2])
     auto child_of = [&](uint32_t k) { uint32_t s = k & 3u; return s == 0 ? c0 : (s == 1 ? c1 : (s == 2 ? c2 : c3)); };
     if (key[0] != 0xffffffffu) {
-        if (key[3] != 0xffffffffu) trav_push(t, lds_stack, spill, child_of(key[3]), st);
-        if (key[2] != 0xffffffffu) trav_push(t, lds_stack, spill, child_of(key[2]), st);
-        if (key[1] != 0xffffffffu) trav_push(t, lds_stack, spill, child_of(key[1]), st);
+#define PT_PUSH_ORDERED(F)                                                                                                          \
+        if (key[3] != 0xffffffffu) trav_push<F>(t, lds_stack, spill, child_of(key[3]), st);                                         \
+        if (key[2] != 0xffffffffu) trav_push<F>(t, lds_stack, spill, child_of(key[2]), st);                                         \
+        if (key[1] != 0xffffffffu) trav_push<F>(t, lds_stack, spill, child_of(key[1]), st);
+        if (shallow) { PT_PUSH_ORDERED(true) } else { PT_PUSH_ORDERED(false) }
+#undef PT_PUSH_ORDERED
         t.cur = child_of(key[0]);
     } else trav_pop(t, lds_stack, spill);
 }
