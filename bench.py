@@ -334,9 +334,9 @@ def main():
 
     if rank == 0:
         if args.save_image:
-            from PIL import Image
+            from gltf_renderer_amd import gltf
             rgb, q = r.tonemap(out, want_rgba8=True)
-            Image.fromarray(q[..., :3]).save(args.save_image)
+            gltf.write_png(args.save_image, q, 3)
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

@@ -1391,4 +1391,20 @@ int img_load_rgb32f(const char* path, int* w, int* h, int* half, float** out) {
 }
 void img_free(void* p) { free(p); }
 
+int img_write_png(const char* path, const uint8_t* rgba8, int width, int height, int channels) {
+    if (!path || !rgba8) return fail(PT_ERR_INVALID_ARGUMENT, "img_write_png: null argument");
+    std::string err;
+    return hostimg::write_png(path, rgba8, width, height, channels, err) ? PT_OK : fail(PT_ERR_INVALID_ARGUMENT, err);
+}
+int img_write_pfm(const char* path, const float* rgb, int width, int height) {
+    if (!path || !rgb) return fail(PT_ERR_INVALID_ARGUMENT, "img_write_pfm: null argument");
+    std::string err;
+    return hostimg::write_pfm(path, rgb, width, height, err) ? PT_OK : fail(PT_ERR_INVALID_ARGUMENT, err);
+}
+int img_write_exr(const char* path, const float* rgb, int width, int height, int half) {
+    if (!path || !rgb) return fail(PT_ERR_INVALID_ARGUMENT, "img_write_exr: null argument");
+    std::string err;
+    return hostimg::write_exr(path, rgb, width, height, half != 0, err) ? PT_OK : fail(PT_ERR_INVALID_ARGUMENT, err);
+}
+
 }  // extern "C"

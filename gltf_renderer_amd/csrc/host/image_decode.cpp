@@ -997,4 +997,181 @@ bool decode_exr(const uint8_t* data, size_t n, ImageF& out, std::string& err, bo
     return true;
 }
 
+// =================================================================================================== writers
+namespace {
+
+uint32_t crc32_update(uint32_t crc, const uint8_t* p, size_t n) {
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1; table[i] = c; }
+        ready = true;
+    }
+    for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xff] ^ (crc >> 8);
+    return crc;
+}
+void put_be32(std::vector<uint8_t>& v, uint32_t x) { v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x); }
+void png_chunk(std::vector<uint8_t>& out, const char* type, const std::vector<uint8_t>& body) {
+    put_be32(out, (uint32_t)body.size());
+    size_t start = out.size();
+    out.insert(out.end(), type, type + 4);
+    out.insert(out.end(), body.begin(), body.end());
+    put_be32(out, crc32_update(0xffffffffu, out.data() + start, out.size() - start) ^ 0xffffffffu);
+}
+// deflate with a greedy hash-chain LZ77 matcher and the fixed Huffman code (RFC 1951 3.2.6): small, dependency-free, and good
+// enough for rendered images (typically 2-4x on 8-bit output)
+struct BitWriter {
+    std::vector<uint8_t>& out; uint32_t acc = 0; int n = 0;
+    explicit BitWriter(std::vector<uint8_t>& o) : out(o) {}
+    void bits(uint32_t v, int c) { acc |= v << n; n += c; while (n >= 8) { out.push_back((uint8_t)acc); acc >>= 8; n -= 8; } }
+    void huff(uint32_t code, int len) { uint32_t r = 0; for (int i = 0; i < len; i++) r |= ((code >> i) & 1u) << (len - 1 - i); bits(r, len); }   // codes go MSB first
+    void flush() { if (n) { out.push_back((uint8_t)acc); acc = 0; n = 0; } }
+};
+void fixed_literal(BitWriter& w, int s) {
+    if (s < 144) w.huff(0x30 + s, 8); else if (s < 256) w.huff(0x190 + (s - 144), 9); else if (s < 280) w.huff(s - 256, 7); else w.huff(0xc0 + (s - 280), 8);
+}
+void zlib_deflate(const uint8_t* src, size_t n, std::vector<uint8_t>& out) {
+    out.push_back(0x78); out.push_back(0x9c);
+    BitWriter w(out);
+    w.bits(1, 1); w.bits(1, 2);                                  // final block, fixed Huffman
+    const int kHashBits = 15, kWindow = 32768, kMaxChain = 32;
+    std::vector<int32_t> head((size_t)1 << kHashBits, -1), prev(n ? n : 1, -1);
+    auto hash = [&](size_t i) { return ((uint32_t)src[i] * 2654435761u ^ (uint32_t)src[i + 1] * 40503u ^ (uint32_t)src[i + 2] * 2246822519u) >> (32 - kHashBits); };
+    size_t i = 0;
+    while (i < n) {
+        int best_len = 0, best_dist = 0;
+        if (i + 3 <= n) {
+            uint32_t h = hash(i);
+            int32_t cand = head[h];
+            int chain = 0;
+            while (cand >= 0 && (int)(i - (size_t)cand) <= kWindow && chain++ < kMaxChain) {
+                int l = 0;
+                const size_t maxl = n - i < 258 ? n - i : 258;
+                while ((size_t)l < maxl && src[(size_t)cand + l] == src[i + l]) l++;
+                if (l > best_len) { best_len = l; best_dist = (int)(i - (size_t)cand); if (l == 258) break; }
+                cand = prev[(size_t)cand];
+            }
+        }
+        const size_t step = best_len >= 3 ? (size_t)best_len : 1;
+        if (best_len >= 3) {
+            int ls = 28;
+            while (kLenBase[ls] > best_len) ls--;
+            fixed_literal(w, 257 + ls);
+            w.bits((uint32_t)(best_len - kLenBase[ls]), kLenExtra[ls]);
+            int ds = 29;
+            while (kDistBase[ds] > best_dist) ds--;
+            w.huff((uint32_t)ds, 5);
+            w.bits((uint32_t)(best_dist - kDistBase[ds]), kDistExtra[ds]);
+        } else fixed_literal(w, src[i]);
+        for (size_t k = 0; k < step; k++, i++)
+            if (i + 3 <= n) { uint32_t h = hash(i); prev[i] = head[h]; head[h] = (int32_t)i; }
+    }
+    fixed_literal(w, 256);
+    w.flush();
+    put_be32(out, adler32(src, n));
+}
+bool write_all(const std::string& path, const std::vector<uint8_t>& bytes, std::string& err) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) { err = "cannot create " + path; return false; }
+    size_t put = fwrite(bytes.data(), 1, bytes.size(), f);
+    fclose(f);
+    if (put != bytes.size()) { err = "short write on " + path; return false; }
+    return true;
+}
+uint16_t float_to_half(float f) {                               // round to nearest even
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    uint32_t sign = (x >> 16) & 0x8000u, mant = x & 0x7fffffu;
+    int exp = (int)((x >> 23) & 0xff) - 127 + 15;
+    if (((x >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (mant ? 0x200u : 0u));
+    if (exp >= 31) return (uint16_t)(sign | 0x7c00u);
+    if (exp <= 0) {
+        if (exp < -10) return (uint16_t)sign;
+        mant |= 0x800000u;
+        int shift = 14 - exp;
+        uint32_t h = mant >> shift, rem = mant & ((1u << shift) - 1), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (h & 1))) h++;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((uint32_t)exp << 10) | (mant >> 13), rem = mant & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) h++;
+    return (uint16_t)(sign | h);
+}
+
+}  // namespace
+
+bool encode_png(const uint8_t* rgba, int w, int h, int channels, std::vector<uint8_t>& out, std::string& err) {
+    if (!rgba || w <= 0 || h <= 0 || (channels != 3 && channels != 4)) { err = "png: bad arguments"; return false; }
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    out.assign(sig, sig + 8);
+    std::vector<uint8_t> ihdr;
+    put_be32(ihdr, (uint32_t)w); put_be32(ihdr, (uint32_t)h);
+    ihdr.push_back(8); ihdr.push_back(channels == 4 ? 6 : 2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    png_chunk(out, "IHDR", ihdr);
+    // filter type 1 (Sub) on every row: cheap and effective on smooth images
+    const size_t stride = (size_t)w * channels;
+    std::vector<uint8_t> raw((stride + 1) * h);
+    for (int y = 0; y < h; y++) {
+        uint8_t* row = &raw[(size_t)y * (stride + 1)];
+        row[0] = 1;
+        const uint8_t* s = rgba + (size_t)y * w * 4;
+        for (int x = 0; x < w; x++)
+            for (int c = 0; c < channels; c++) {
+                uint8_t cur = s[x * 4 + c], left = x ? s[(x - 1) * 4 + c] : 0;
+                row[1 + (size_t)x * channels + c] = (uint8_t)(cur - left);
+            }
+    }
+    std::vector<uint8_t> z;
+    zlib_deflate(raw.data(), raw.size(), z);
+    png_chunk(out, "IDAT", z);
+    png_chunk(out, "IEND", {});
+    return true;
+}
+bool write_png(const std::string& path, const uint8_t* rgba, int w, int h, int channels, std::string& err) {
+    std::vector<uint8_t> bytes;
+    return encode_png(rgba, w, h, channels, bytes, err) && write_all(path, bytes, err);
+}
+// Portable float map "PF": little-endian RGB32F, bottom row first
+bool write_pfm(const std::string& path, const float* rgb, int w, int h, std::string& err) {
+    if (!rgb || w <= 0 || h <= 0) { err = "pfm: bad arguments"; return false; }
+    char head[64];
+    int n = snprintf(head, sizeof(head), "PF\n%d %d\n-1.0\n", w, h);
+    std::vector<uint8_t> bytes(head, head + n);
+    for (int y = h - 1; y >= 0; y--) { const uint8_t* row = (const uint8_t*)(rgb + (size_t)y * w * 3); bytes.insert(bytes.end(), row, row + (size_t)w * 12); }
+    return write_all(path, bytes, err);
+}
+// OpenEXR, single part, scan lines, no compression, channels B G R (HALF or FLOAT)
+bool write_exr(const std::string& path, const float* rgb, int w, int h, bool half, std::string& err) {
+    if (!rgb || w <= 0 || h <= 0) { err = "exr: bad arguments"; return false; }
+    std::vector<uint8_t> o;
+    auto le32 = [&](uint32_t v) { for (int i = 0; i < 4; i++) o.push_back((uint8_t)(v >> (8 * i))); };
+    auto le64 = [&](uint64_t v) { for (int i = 0; i < 8; i++) o.push_back((uint8_t)(v >> (8 * i))); };
+    auto str = [&](const char* s) { o.insert(o.end(), s, s + strlen(s) + 1); };
+    auto f32 = [&](float f) { uint32_t u; memcpy(&u, &f, 4); le32(u); };
+    le32(20000630u); le32(2u);
+    str("channels"); str("chlist"); le32(3 * 18 + 1);
+    for (const char* c : {"B", "G", "R"}) { str(c); le32(half ? 1u : 2u); o.push_back(0); o.push_back(0); o.push_back(0); o.push_back(0); le32(1); le32(1); }
+    o.push_back(0);
+    str("compression"); str("compression"); le32(1); o.push_back(0);
+    str("dataWindow"); str("box2i"); le32(16); le32(0); le32(0); le32((uint32_t)(w - 1)); le32((uint32_t)(h - 1));
+    str("displayWindow"); str("box2i"); le32(16); le32(0); le32(0); le32((uint32_t)(w - 1)); le32((uint32_t)(h - 1));
+    str("lineOrder"); str("lineOrder"); le32(1); o.push_back(0);
+    str("pixelAspectRatio"); str("float"); le32(4); f32(1.0f);
+    str("screenWindowCenter"); str("v2f"); le32(8); f32(0.0f); f32(0.0f);
+    str("screenWindowWidth"); str("float"); le32(4); f32(1.0f);
+    o.push_back(0);
+    const size_t px = half ? 2 : 4, line = (size_t)w * 3 * px, table = o.size();
+    for (int y = 0; y < h; y++) le64((uint64_t)(table + (size_t)h * 8 + (size_t)y * (8 + line)));
+    for (int y = 0; y < h; y++) {
+        le32((uint32_t)y); le32((uint32_t)line);
+        for (int c = 2; c >= 0; c--)                                // B, G, R
+            for (int x = 0; x < w; x++) {
+                float v = rgb[((size_t)y * w + x) * 3 + c];
+                if (half) { uint16_t hv = float_to_half(v); o.push_back((uint8_t)hv); o.push_back((uint8_t)(hv >> 8)); }
+                else f32(v);
+            }
+    }
+    return write_all(path, o, err);
+}
+
 }  // namespace hostimg

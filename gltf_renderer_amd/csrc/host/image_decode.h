@@ -32,6 +32,12 @@ bool decode_hdr(const uint8_t* data, size_t n, ImageF& out, std::string& err);
 // single_channel: the lookup-table loader's rules (GpuResources.cpp:72-132: one HALF channel, replicated into r, g, b)
 bool decode_exr(const uint8_t* data, size_t n, ImageF& out, std::string& err, bool single_channel = false);
 bool read_file(const std::string& path, std::vector<uint8_t>& out, std::string& err);
+// writers: PNG from RGBA8 rows (3 or 4 channels kept; own deflate: LZ77 + fixed Huffman), PFM and uncompressed
+// scan-line OpenEXR (HALF or FLOAT, channels B G R) from RGB32F
+bool encode_png(const uint8_t* rgba, int w, int h, int channels, std::vector<uint8_t>& out, std::string& err);
+bool write_png(const std::string& path, const uint8_t* rgba, int w, int h, int channels, std::string& err);
+bool write_pfm(const std::string& path, const float* rgb, int w, int h, std::string& err);
+bool write_exr(const std::string& path, const float* rgb, int w, int h, bool half, std::string& err);
 float half_to_float(uint16_t h);
 
 }  // namespace hostimg

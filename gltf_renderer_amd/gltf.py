@@ -13,7 +13,7 @@ SCENE_EXPORTS = ["gs_load_file", "gs_free", "gs_last_error", "gs_get_counts", "g
                  "gs_get_texture", "gs_get_sampler", "gs_get_node", "gs_get_node_weights", "gs_get_scene_nodes", "gs_get_skin", "gs_get_animation",
                  "gs_get_channel", "gs_sample_channel", "gs_apply_rest_transforms", "gs_animate", "gs_calculate_global_transforms", "gs_player_tick",
                  "gs_gather_lights", "gs_gather_bones", "gs_upload", "gs_frame", "img_load_rgba8", "img_decode_rgba8", "img_load_rgb32f",
-                 "img_decode_rgb32f", "img_free"]
+                 "img_decode_rgb32f", "img_free", "img_write_png", "img_write_pfm", "img_write_exr"]
 
 
 class GsCounts(C.Structure):
@@ -265,3 +265,28 @@ def decode_rgb32f(data, is_exr):
 def load_rgb32f(path):
     with open(path, "rb") as f:
         return decode_rgb32f(f.read(), str(path).lower().endswith(".exr"))
+
+
+def write_png(path, rgba8, channels=3):
+    """(H, W, 4) uint8 (pt_tonemap's RGBA8) -> PNG file; channels = 3 drops alpha."""
+    L = _lib()
+    a = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    rc = L.img_write_png(str(path).encode(), a.ctypes.data_as(C.c_void_p), C.c_int(a.shape[1]), C.c_int(a.shape[0]), C.c_int(channels))
+    if rc != 0:
+        _err(L, rc)
+
+
+def write_pfm(path, rgb32f):
+    L = _lib()
+    a = np.ascontiguousarray(rgb32f, dtype=np.float32)
+    rc = L.img_write_pfm(str(path).encode(), a.ctypes.data_as(C.c_void_p), C.c_int(a.shape[1]), C.c_int(a.shape[0]))
+    if rc != 0:
+        _err(L, rc)
+
+
+def write_exr(path, rgb32f, half=False):
+    L = _lib()
+    a = np.ascontiguousarray(rgb32f, dtype=np.float32)
+    rc = L.img_write_exr(str(path).encode(), a.ctypes.data_as(C.c_void_p), C.c_int(a.shape[1]), C.c_int(a.shape[0]), C.c_int(int(half)))
+    if rc != 0:
+        _err(L, rc)

@@ -114,6 +114,12 @@ int img_decode_rgba8(const void* data, size_t bytes, int* width, int* height, ui
 int img_load_rgb32f(const char* path, int* width, int* height, int* half_source_out, float** rgb_out);
 int img_decode_rgb32f(const void* data, size_t bytes, int is_exr, int* width, int* height, int* half_source_out, float** rgb_out);
 void img_free(void* p);
+/* Image writers for offline output (the reference only presents to a swap chain): 8-bit PNG of the tone-mapped
+ * frame (pt_tonemap's RGBA8; channels = 3 drops alpha), and the linear RGB32F radiance as PFM or uncompressed scan-line
+ * OpenEXR (half != 0: HALF channels). */
+int img_write_png(const char* path, const uint8_t* rgba8, int width, int height, int channels);
+int img_write_pfm(const char* path, const float* rgb32f, int width, int height);
+int img_write_exr(const char* path, const float* rgb32f, int width, int height, int half);
 
 #ifdef __cplusplus
 }

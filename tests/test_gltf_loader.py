@@ -663,3 +663,35 @@ def test_exported_procedural_scene_round_trips_through_the_loader(tmp_path):
         gd = np.array(got.direction[:], np.float64)
         assert np.allclose(got.position[:], want.position[:], atol=1e-6) and np.allclose(gd / np.linalg.norm(gd), want.direction[:], atol=1e-6)
         assert np.allclose(got.color[:], want.color[:]) and got.inner_angle == want.inner_angle and got.outer_angle == want.outer_angle
+
+
+def test_image_writers_round_trip(tmp_path):
+    """N3: PNG (own LZ77 + fixed-Huffman deflate), PFM and OpenEXR writers, read back by an independent decoder (PIL / numpy)
+    and by the library's own readers."""
+    rng = np.random.default_rng(21)
+    smooth = np.concatenate([smooth_image(rng, 70, 93, 3), rng.integers(0, 256, (70, 93, 1)).astype(np.uint8)], -1)
+    noisy = rng.integers(0, 256, (31, 17, 4)).astype(np.uint8)
+    flat = np.full((40, 300, 4), 200, np.uint8)                    # long runs: matches of length 258, distance 1
+    for name, img in (("smooth", smooth), ("noisy", noisy), ("flat", flat)):
+        for ch in (3, 4):
+            p = tmp_path / ("%s_%d.png" % (name, ch))
+            G.write_png(p, img, ch)
+            ref = np.asarray(PIL.open(p))
+            assert ref.shape == img.shape[:2] + (ch,) and np.array_equal(ref, img[..., :ch]), (name, ch)
+            back = G.load_rgba8(str(p))
+            assert np.array_equal(back[..., :ch], img[..., :ch]) and (ch == 4 or np.all(back[..., 3] == 255))
+    assert os.path.getsize(tmp_path / "flat_4.png") < flat.nbytes // 50            # the LZ77 matcher works (runs collapse)
+    hdr = (rng.random((23, 37, 3)) ** 6 * 1e4).astype(np.float32)
+    hdr[0, 0] = (0, 1e-8, 65504.0)
+    G.write_pfm(tmp_path / "r.pfm", hdr)
+    raw = open(tmp_path / "r.pfm", "rb").read()
+    head = b"PF\n37 23\n-1.0\n"
+    assert raw.startswith(head) and np.array_equal(np.frombuffer(raw[len(head):], "<f4").reshape(23, 37, 3)[::-1], hdr)
+    G.write_exr(tmp_path / "f.exr", hdr, half=False)
+    got, half = G.load_rgb32f(str(tmp_path / "f.exr"))
+    assert not half and np.array_equal(got, hdr)
+    G.write_exr(tmp_path / "h.exr", hdr, half=True)
+    got, half = G.load_rgb32f(str(tmp_path / "h.exr"))
+    assert half and np.array_equal(got, hdr.astype(np.float16).astype(np.float32))       # round to nearest even, like numpy
+    with pytest.raises(MiptError):
+        G.write_png(tmp_path / "no_such_dir" / "x.png", smooth)

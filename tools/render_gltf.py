@@ -84,8 +84,12 @@ def main():
         r.trace(st, p, out)
     torch.cuda.synchronize()
     _, rgba8 = r.tonemap(out, want_rgba8=True)
-    from PIL import Image
-    Image.fromarray(rgba8[..., :3]).save(a.out)
+    if a.out.lower().endswith(".exr"):
+        gltf.write_exr(a.out, r.readback(out)[..., :3], half=True)       # linear radiance
+    elif a.out.lower().endswith(".pfm"):
+        gltf.write_pfm(a.out, r.readback(out)[..., :3])
+    else:
+        gltf.write_png(a.out, rgba8, 3)                                  # tone-mapped (AgX + sRGB), ToneMapper.ps.hlsl
     s = r.stats()
     print("%s: %d triangles, %d lights, %d spp, %.2f ms/frame, %.0f Mrays/s -> %s" % (a.path, s.bvh_triangles, lights, a.spp, s.trace_ms, s.rays / max(s.trace_ms, 1e-9) / 1e3 / max(a.spp, 1) * 1.0, a.out))
 
