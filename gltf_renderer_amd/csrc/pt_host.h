@@ -22,6 +22,7 @@ struct AccelScratch {
     uint32_t* widx = nullptr;        // exclusive scan of kept = wide node index
     void* scan_temp = nullptr;
     size_t scan_temp_bytes = 0;
+    uint32_t* collapse_counters = nullptr;   // greedy collapse: [0] next frontier size, [1] wide nodes allocated
     size_t capacity = 0;
 };
 void accel_scratch_free(AccelScratch& s);
