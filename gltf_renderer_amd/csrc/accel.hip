@@ -143,6 +143,8 @@ __global__ __launch_bounds__(256) void k_hierarchy(const uint64_t* __restrict__ 
     int right = (max(i, j) == gamma + 1) ? ~(gamma + 1) : (gamma + 1);
     nodes[i].child0 = left;
     nodes[i].child1 = right;
+    nodes[i]._pad[0] = (uint32_t)min(i, j);                    // the sorted-triangle range this subtree covers: first, count
+    nodes[i]._pad[1] = (uint32_t)(max(i, j) - min(i, j) + 1);
     if (left < 0) leaf_parent[gamma] = i * 2; else node_parent[gamma] = i * 2;
     if (right < 0) leaf_parent[gamma + 1] = i * 2 + 1; else node_parent[gamma + 1] = i * 2 + 1;
     if (i == 0) node_parent[0] = -1;
@@ -245,8 +247,15 @@ __global__ __launch_bounds__(256) void k_collapse_level(const BvhNode* __restric
                                                         uint32_t* __restrict__ widx_out, uint32_t* __restrict__ counters, Bvh4Node* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_in) return;
+    // an inner subtree of at most kLeafMax triangles becomes ONE leaf reference (its triangles are contiguous): the bottom of a
+    // binary tree is full of 2- and 3-triangle subtrees, which as wide nodes would spend a whole node step on two boxes
+    auto child_ref = [&](int32_t r) -> int32_t {
+        if (r < 0) return r;
+        const uint32_t first = nodes2[r]._pad[0], count = nodes2[r]._pad[1];
+        return count <= (uint32_t)kLeafMax ? ~(int32_t)(first | ((count - 1u) << 28)) : r;
+    };
     const BvhNode& n = nodes2[frontier_in[i]];
-    int32_t ref[4] = {n.child0, n.child1, kEmptyChild, kEmptyChild};
+    int32_t ref[4] = {child_ref(n.child0), child_ref(n.child1), kEmptyChild, kEmptyChild};
     float lo[4][3], hi[4][3];
     for (int a = 0; a < 3; a++) { lo[0][a] = n.lo0[a]; hi[0][a] = n.hi0[a]; lo[1][a] = n.lo1[a]; hi[1][a] = n.hi1[a]; }
     int cnt = 2;
@@ -261,7 +270,7 @@ __global__ __launch_bounds__(256) void k_collapse_level(const BvhNode* __restric
         }
         if (pick < 0) break;
         const BvhNode& m = nodes2[ref[pick]];
-        ref[pick] = m.child0; ref[cnt] = m.child1;
+        ref[pick] = child_ref(m.child0); ref[cnt] = child_ref(m.child1);
         for (int a = 0; a < 3; a++) { lo[pick][a] = m.lo0[a]; hi[pick][a] = m.hi0[a]; lo[cnt][a] = m.lo1[a]; hi[cnt][a] = m.hi1[a]; }
         cnt++;
     }

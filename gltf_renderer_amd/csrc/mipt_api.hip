@@ -560,7 +560,7 @@ int pt_scene_set_instances(pt_ctx* ctx, const pt_instance_desc* in, int count) {
         r.tri_offset = (uint32_t)tris;
         r.tri_count = d.num_of_indices / 3;
         tris += r.tri_count;
-        if (tris > 0x7fffffffull) return ctx->fail(PT_ERR_CAPACITY, "too many triangles");
+        if (tris > 0x0fffffffull) return ctx->fail(PT_ERR_CAPACITY, "too many triangles (leaf references hold 28 bits of triangle index)");
         recs.push_back(r);
     }
     ctx->instances.swap(recs);

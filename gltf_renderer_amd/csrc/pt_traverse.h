@@ -146,16 +146,19 @@ PT_DEV void trav_node_step(Trav& t, const SceneRec& sc, int* lds_stack, int* spi
     } else trav_pop(t, lds_stack, spill);
 }
 
-// One leaf step: t.cur = ~triangle on entry; on exit the popped entry or kTravDone.
+// One leaf step: t.cur = leaf reference (1..kLeafMax contiguous triangles) on entry; on exit the popped entry or kTravDone.
 template <bool COUNT>
 PT_DEV void trav_leaf_step(Trav& t, const SceneRec& sc, const int* lds_stack, const int* spill, LaneStats& st) {
-    const int tri = ~t.cur;
+    const uint32_t leaf = (uint32_t)~t.cur;
+    const int first = (int)(leaf & kLeafFirstMask), count = (int)(leaf >> 28) + 1;
+    bool stop = false;
+  for (int k = 0; k < count && !stop; k++) {
+    const int tri = first + k;
     const float4* tp = (const float4*)sc.tris + (size_t)tri * 3;
     float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
     if (COUNT) st.tris++;
     vec3 v0 = v3(q0.x, q0.y, q0.z), e1 = v3(q1.x, q1.y, q1.z), e2 = v3(q2.x, q2.y, q2.z);
     uint32_t tflags = __float_as_uint(q2.w);
-    bool stop = false;
     // Moeller-Trumbore, barycentrics (u, v) = weights of vertex 1 and 2
     vec3 p = cross(t.d, e2);
     float det = dot(e1, p);
@@ -191,6 +194,7 @@ PT_DEV void trav_leaf_step(Trav& t, const SceneRec& sc, const int* lds_stack, co
             }
         }
     }
+  }
     if (stop) t.cur = kTravDone;
     else trav_pop(t, lds_stack, spill);
 }
