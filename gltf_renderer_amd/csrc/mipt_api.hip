@@ -192,6 +192,7 @@ public:
             SceneRec sc;
             memset(&sc, 0, sizeof(sc));
             sc.rmats = ctx->d_rmats; sc.lights = ctx->d_lights; sc.instances = ctx->d_instances;
+            sc.n_materials = (uint32_t)ctx->n_materials; sc.n_instances = (uint32_t)ctx->instances.size();
             sc.nodes = ctx->d_nodes; sc.tris = ctx->d_tris; sc.root = ctx->root; sc.num_tris = ctx->n_tris;
             sc.sheen_e = ctx->d_sheen; sc.srgb_lut = ctx->d_srgb;
             sc.has_env = 0;

@@ -270,6 +270,36 @@ PT_DEV MatHeader load_mat_header(const RMat* m) {
     return r;
 }
 PT_DEV bool slot_bound(uint32_t mask, int slot) { return (mask >> slot) & 1u; }
+// The shade stage gathers 17 dwordx4 of material data per hit (header + the albedo / normal / metal-rough slots) from a table
+// of a few dozen records; that stage is bound by the issue rate of its vector-memory instructions, so a kernel built with
+// PT_LUT_LDS keeps those 272 B of every material in LDS when the scene has few enough and reads them with ds_read instead.
+#ifdef PT_LUT_LDS
+constexpr uint32_t kMatCacheMax = 96;
+constexpr uint32_t kMatCacheRecs = 17;                     // float4 per material: 8 header + 3 slots x 3
+static __shared__ float4 pt_lds_mat[kMatCacheMax * kMatCacheRecs];
+PT_DEV bool materials_cached(const SceneRec& sc) { return sc.n_materials <= kMatCacheMax; }
+PT_DEV void stage_materials(const SceneRec& sc) {          // call once per workgroup, all threads
+    if (materials_cached(sc)) {
+        const uint32_t total = sc.n_materials * kMatCacheRecs;
+        for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
+            const uint32_t m = i / kMatCacheRecs, k = i - m * kMatCacheRecs;
+            pt_lds_mat[i] = ((const float4*)(sc.rmats + m))[k];
+        }
+    }
+    __syncthreads();
+}
+PT_DEV MatHeader material_header(const SceneRec& sc, uint32_t mid) {
+    if (materials_cached(sc)) return load_mat_header((const RMat*)(pt_lds_mat + mid * kMatCacheRecs));
+    return load_mat_header(sc.rmats + mid);
+}
+PT_DEV RTex material_slot012(const SceneRec& sc, uint32_t mid, int slot) {       // slots 0..2 only (normal, albedo, metal-rough)
+    if (materials_cached(sc)) return load_rtex((const RTex*)(pt_lds_mat + mid * kMatCacheRecs + 8 + 3 * slot));
+    return load_rtex(&sc.rmats[mid].tex[slot]);
+}
+#else
+PT_DEV MatHeader material_header(const SceneRec& sc, uint32_t mid) { return load_mat_header(sc.rmats + mid); }
+PT_DEV RTex material_slot012(const SceneRec& sc, uint32_t mid, int slot) { return load_rtex(&sc.rmats[mid].tex[slot]); }
+#endif
 // GetBaseColor + GetAlpha for the any-hit paths (Material.hlsli:98-117); only the fields they need are loaded.
 PT_DEV void base_color_alpha(const SceneRec& sc, const RMat* m, const vec2 tc[2], vec4 vc, unsigned& taps, float& base_alpha, float& alpha, float& cutoff) {
     const float4* q = (const float4*)m;
@@ -301,7 +331,8 @@ PT_DEV Surface get_surface(const SceneRec& sc, uint32_t flags, const RMat* m, co
     Surface s;
     // The three usual PBR textures are fetched as ONE batch: their slot records are loaded together, their twelve texel
     // gathers are issued together (unbound slots read a 1x1 white texel, so there is no branch to split the batch).
-    const RTex t_alb = load_rtex(&m->tex[SLOT_ALBEDO]), t_nrm = load_rtex(&m->tex[SLOT_NORMAL]), t_mr = load_rtex(&m->tex[SLOT_METALLIC_ROUGHNESS]);
+    const uint32_t mid = (uint32_t)(m - sc.rmats);
+    const RTex t_alb = material_slot012(sc, mid, SLOT_ALBEDO), t_nrm = material_slot012(sc, mid, SLOT_NORMAL), t_mr = material_slot012(sc, mid, SLOT_METALLIC_ROUGHNESS);
     const TexTaps k_alb = texture_taps(t_alb, a.tc), k_nrm = texture_taps(t_nrm, a.tc), k_mr = texture_taps(t_mr, a.tc);
     const uint32_t a00 = gload(k_alb.p00), a10 = gload(k_alb.p10), a01 = gload(k_alb.p01), a11 = gload(k_alb.p11);
     const uint32_t n00 = gload(k_nrm.p00), n10 = gload(k_nrm.p10), n01 = gload(k_nrm.p01), n11 = gload(k_nrm.p11);

@@ -124,6 +124,7 @@ struct EnvRec {
 
 struct SceneRec {
     const RMat* rmats;          // resolved materials (index = material_id)
+    uint32_t n_materials, n_instances;
     const pt_light* lights;
     const InstanceRec* instances;
     const Bvh4Node* nodes;
