@@ -159,6 +159,32 @@ __global__ __launch_bounds__(256) void k_reorder(const TriPacket* __restrict__ i
     d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
 }
 
+// 3c. the shading packet of every (sorted) triangle: de-index the instance's streams once, here, instead of at every hit
+__global__ __launch_bounds__(256) void k_shade_packets(const TriPacket* __restrict__ tris, uint32_t n, const InstanceRec* __restrict__ instances,
+                                                       ShadePacket* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const InstanceRec& in = instances[tris[i].inst];
+    const uint32_t prim = tris[i].prim;
+    ShadePacket p;
+    memset(&p, 0, sizeof(p));
+    for (int k = 0; k < 3; k++) {
+        uint32_t v = prim * 3 + k;
+        if (in.p_index) v = in.index_is16 ? (uint32_t)((const uint16_t*)in.p_index)[v] : ((const uint32_t*)in.p_index)[v];
+        ShadePacket::V& o = p.v[k];
+        const float* q = in.p_position + (size_t)v * 3;
+        o.pos[0] = q[0]; o.pos[1] = q[1]; o.pos[2] = q[2];
+        if (in.p_tangent_space) o.tangent_space = in.p_tangent_space[v];
+        if (in.p_texcoord[0]) { float2 t = in.p_texcoord[0][v]; o.uv0[0] = t.x; o.uv0[1] = t.y; }
+        if (in.p_texcoord[1]) { float2 t = in.p_texcoord[1][v]; o.uv1[0] = t.x; o.uv1[1] = t.y; }
+        if (in.p_color) { uint2 c = in.p_color[v]; o.color[0] = c.x; o.color[1] = c.y; }
+    }
+    const float4* s = (const float4*)&p;
+    float4* d = (float4*)(out + i);
+#pragma unroll
+    for (int q = 0; q < 8; q++) d[q] = s[q];
+}
+
 // 5. bottom-up fit.  parent codes are node*2 + slot.
 __global__ __launch_bounds__(256) void k_fit(const TriPacket* __restrict__ tris, uint32_t n, BvhNode* nodes, const int32_t* __restrict__ node_parent,
                                              const int32_t* __restrict__ leaf_parent, uint32_t* flags) {
@@ -343,7 +369,7 @@ void accel_scratch_free(AccelScratch& s) {
 }
 
 hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const InstanceRec* d_instances, int n_inst, uint32_t n_tris, Bvh4Node* d_nodes,
-                       TriPacket* d_tris, int32_t* root_out, uint32_t* wide_nodes_out, hipStream_t stream) {
+                       TriPacket* d_tris, ShadePacket* d_shade, int32_t* root_out, uint32_t* wide_nodes_out, hipStream_t stream) {
     *root_out = 0;
     *wide_nodes_out = 0;
     if (n_tris == 0) return hipSuccess;
@@ -354,12 +380,15 @@ hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const Instan
     hipLaunchKernelGGL(k_setup, dim3(g), dim3(256), 0, stream, d_buffers, d_instances, n_inst, n_tris, s.tris_unsorted, s.bounds);
     if (n_tris == 1) {
         *root_out = ~0;
-        return hipMemcpyAsync(d_tris, s.tris_unsorted, sizeof(TriPacket), hipMemcpyDeviceToDevice, stream);
+        if ((e = hipMemcpyAsync(d_tris, s.tris_unsorted, sizeof(TriPacket), hipMemcpyDeviceToDevice, stream))) return e;
+        hipLaunchKernelGGL(k_shade_packets, dim3(1), dim3(256), 0, stream, d_tris, 1u, d_instances, d_shade);
+        return hipGetLastError();
     }
     hipLaunchKernelGGL(k_morton, dim3(g), dim3(256), 0, stream, s.tris_unsorted, n_tris, s.bounds, s.keys_a, s.vals_a);
     size_t tb = s.sort_temp_bytes;
     if ((e = rocprim::radix_sort_pairs(s.sort_temp, tb, s.keys_a, s.keys_b, s.vals_a, s.vals_b, (size_t)n_tris, 0, 63, stream))) return e;
     hipLaunchKernelGGL(k_reorder, dim3(g), dim3(256), 0, stream, s.tris_unsorted, s.vals_b, n_tris, d_tris);
+    hipLaunchKernelGGL(k_shade_packets, dim3(g), dim3(256), 0, stream, d_tris, n_tris, d_instances, d_shade);
     if ((e = hipMemsetAsync(s.flags, 0, (size_t)n_tris * 4, stream))) return e;
     hipLaunchKernelGGL(k_hierarchy, dim3(g), dim3(256), 0, stream, s.keys_b, (int)n_tris, s.nodes2, s.node_parent, s.leaf_parent);
     hipLaunchKernelGGL(k_fit, dim3(g), dim3(256), 0, stream, d_tris, n_tris, s.nodes2, s.node_parent, s.leaf_parent, s.flags);

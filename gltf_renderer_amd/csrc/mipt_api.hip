@@ -42,7 +42,7 @@ struct pt_ctx {
     std::vector<InstanceRec> instances;
     InstanceRec* d_instances = nullptr; size_t instances_cap = 0;
     uint32_t n_tris = 0;
-    Bvh4Node* d_nodes = nullptr; TriPacket* d_tris = nullptr; size_t accel_cap = 0;
+    Bvh4Node* d_nodes = nullptr; TriPacket* d_tris = nullptr; ShadePacket* d_shade = nullptr; size_t accel_cap = 0;
     uint32_t wide_nodes = 0;
     int32_t root = 0;
     AccelScratch scratch;
@@ -159,15 +159,16 @@ public:
         HIPOK(upload_table(ctx->d_instances, ctx->instances_cap, ctx->instances, ctx->stream));
         size_t need = ctx->n_tris ? ctx->n_tris : 1;
         if (need > ctx->accel_cap) {
-            hipFree(ctx->d_nodes); hipFree(ctx->d_tris);
-            ctx->d_nodes = nullptr; ctx->d_tris = nullptr;
+            hipFree(ctx->d_nodes); hipFree(ctx->d_tris); hipFree(ctx->d_shade);
+            ctx->d_nodes = nullptr; ctx->d_tris = nullptr; ctx->d_shade = nullptr;
             size_t cap = need + need / 8 + 64;
             HIPOK(hipMalloc((void**)&ctx->d_nodes, cap * sizeof(Bvh4Node)));
             HIPOK(hipMalloc((void**)&ctx->d_tris, cap * sizeof(TriPacket)));
+            HIPOK(hipMalloc((void**)&ctx->d_shade, cap * sizeof(ShadePacket)));
             ctx->accel_cap = cap;
         }
         HIPOK(hipEventRecord(ctx->ev_accel[0], ctx->stream));
-        HIPOK(accel_build(ctx->scratch, ctx->d_buffers, ctx->d_instances, (int)ctx->instances.size(), ctx->n_tris, ctx->d_nodes, ctx->d_tris,
+        HIPOK(accel_build(ctx->scratch, ctx->d_buffers, ctx->d_instances, (int)ctx->instances.size(), ctx->n_tris, ctx->d_nodes, ctx->d_tris, ctx->d_shade,
                           &ctx->root, &ctx->wide_nodes, ctx->stream));
         HIPOK(hipEventRecord(ctx->ev_accel[1], ctx->stream));
         ctx->have_accel = true;
@@ -193,7 +194,7 @@ public:
             memset(&sc, 0, sizeof(sc));
             sc.rmats = ctx->d_rmats; sc.lights = ctx->d_lights; sc.instances = ctx->d_instances;
             sc.n_materials = (uint32_t)ctx->n_materials; sc.n_instances = (uint32_t)ctx->instances.size();
-            sc.nodes = ctx->d_nodes; sc.tris = ctx->d_tris; sc.root = ctx->root; sc.num_tris = ctx->n_tris;
+            sc.nodes = ctx->d_nodes; sc.tris = ctx->d_tris; sc.shade = ctx->d_shade; sc.root = ctx->root; sc.num_tris = ctx->n_tris;
             sc.sheen_e = ctx->d_sheen; sc.srgb_lut = ctx->d_srgb;
             sc.has_env = 0;
             if (ep->environment_map >= 0) {
@@ -391,7 +392,7 @@ void pt_destroy(pt_ctx* ctx) {
     for (auto& t : ctx->textures) hipFree((void*)t.texels);
     for (auto* e : ctx->envs) { env_free(*e); delete e; }
     hipFree(ctx->d_buffers); hipFree(ctx->d_white); hipFree(ctx->d_rmats); hipFree(ctx->d_lights);
-    hipFree(ctx->d_instances); hipFree(ctx->d_nodes); hipFree(ctx->d_tris); hipFree(ctx->d_sheen); hipFree(ctx->d_srgb); hipFree(ctx->d_counters);
+    hipFree(ctx->d_instances); hipFree(ctx->d_nodes); hipFree(ctx->d_tris); hipFree(ctx->d_shade); hipFree(ctx->d_sheen); hipFree(ctx->d_srgb); hipFree(ctx->d_counters);
     accel_scratch_free(ctx->scratch);
     hipFree(ctx->d_bones);
     hipFree(ctx->d_workspace);

@@ -26,9 +26,10 @@ struct AccelScratch {
     size_t capacity = 0;
 };
 void accel_scratch_free(AccelScratch& s);
-// Builds the 4-wide BVH (<= n_tris nodes) and the sorted packets (n_tris).  root_out: 0, or ~0 for a single triangle.
+// Builds the 4-wide BVH (<= n_tris nodes), the sorted intersection packets and their shading packets (n_tris each).
+// root_out: 0, or ~0 for a single triangle.
 hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const InstanceRec* d_instances, int n_inst, uint32_t n_tris, Bvh4Node* d_nodes,
-                       TriPacket* d_tris, int32_t* root_out, uint32_t* wide_nodes_out, hipStream_t stream);
+                       TriPacket* d_tris, ShadePacket* d_shade, int32_t* root_out, uint32_t* wide_nodes_out, hipStream_t stream);
 
 // ---- envmap.hip -------------------------------------------------------------------------------
 struct EnvDevice {

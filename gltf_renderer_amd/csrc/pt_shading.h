@@ -166,27 +166,33 @@ PT_DEV vec4 sample_slot(const SceneRec& sc, const RMat* m, int slot, const vec2 
 }
 
 // ---------------------------------------------------------------- vertex fetch (PathTracer.lib.hlsl:176-302)
-PT_DEV void fetch_indices(const InstanceRec& in, uint32_t prim, uint32_t v[3]) {                   // :176-184
-    v[0] = prim * 3; v[1] = prim * 3 + 1; v[2] = prim * 3 + 2;
-    if (in.p_index) {
-        if (in.index_is16) {
-            const uint16_t* p = (const uint16_t*)in.p_index;
-            v[0] = gload(p + v[0]); v[1] = gload(p + v[1]); v[2] = gload(p + v[2]);
-        } else {
-            const uint32_t* p = (const uint32_t*)in.p_index;
-            v[0] = gload(p + v[0]); v[1] = gload(p + v[1]); v[2] = gload(p + v[2]);
-        }
+// The three vertices of a hit triangle from its 128-B shading packet (pt_types.h ShadePacket: one cache line, 8 x dwordx4).
+struct PacketVerts { vec3 p[3]; uint32_t ts[3]; float2 uv0[3], uv1[3]; uint2 col[3]; };
+PT_DEV PacketVerts load_shade_packet(const ShadePacket* pk) {
+    const float4* q = (const float4*)pk;
+    const float4 r[8] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]};
+    auto f = [&](int i) { const float4 v = r[i >> 2]; return (i & 3) == 0 ? v.x : ((i & 3) == 1 ? v.y : ((i & 3) == 2 ? v.z : v.w)); };
+    PacketVerts o;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int b = 10 * k;
+        o.p[k] = v3(f(b), f(b + 1), f(b + 2));
+        o.ts[k] = __float_as_uint(f(b + 3));
+        o.uv0[k] = make_float2(f(b + 4), f(b + 5));
+        o.uv1[k] = make_float2(f(b + 6), f(b + 7));
+        o.col[k] = make_uint2(__float_as_uint(f(b + 8)), __float_as_uint(f(b + 9)));
     }
+    return o;
 }
-PT_DEV vec4 fetch_vertex_color(const InstanceRec& in, const uint32_t v[3], vec3 w) {                 // :229-242
+PT_DEV vec4 fetch_vertex_color(const InstanceRec& in, const PacketVerts& pv, vec3 w) {                // :229-242
     if (!in.p_color) return {1, 1, 1, 1};
-    const uint2 q0 = gload_u2(in.p_color + v[0]), q1 = gload_u2(in.p_color + v[1]), q2 = gload_u2(in.p_color + v[2]);
+    const uint2 q0 = pv.col[0], q1 = pv.col[1], q2 = pv.col[2];
     auto un = [](uint2 q) { return vec4{(float)(q.x & 0xffff) / 65535.f, (float)(q.x >> 16) / 65535.f, (float)(q.y & 0xffff) / 65535.f, (float)(q.y >> 16) / 65535.f}; };
     return un(q0) * w.x + un(q1) * w.y + un(q2) * w.z;
 }
-PT_DEV vec2 fetch_texcoord(const float2* p, const uint32_t v[3], vec3 w) {                           // :244-257
-    if (!p) return {0, 0};
-    float2 a = gload_f2(p + v[0]), b = gload_f2(p + v[1]), c = gload_f2(p + v[2]);
+PT_DEV vec2 fetch_texcoord(bool present, const float2 t[3], vec3 w) {                                // :244-257
+    if (!present) return {0, 0};
+    const float2 a = t[0], b = t[1], c = t[2];
     return {w.x * a.x + w.y * b.x + w.z * c.x, w.x * a.y + w.y * b.y + w.z * c.y};
 }
 struct HitGeom {                       // VertexAttributes, PathTracer.lib.hlsl:270-278
@@ -195,20 +201,15 @@ struct HitGeom {                       // VertexAttributes, PathTracer.lib.hlsl:
     vec4 color;
     vec2 tc[2];
 };
-PT_DEV HitGeom get_vertex_attributes(const InstanceRec& in, uint32_t prim, vec3 w) {                 // :280-302
+PT_DEV HitGeom get_vertex_attributes(const InstanceRec& in, const ShadePacket* pk, vec3 w) {         // :280-302
     HitGeom a;
-    uint32_t v[3];
-    fetch_indices(in, prim, v);
-    // issue every stream's gathers before using any of them (one memory round trip for all attributes)
-    const float* pp = in.p_position;
-    const float *q0 = pp + (size_t)v[0] * 3, *q1 = pp + (size_t)v[1] * 3, *q2 = pp + (size_t)v[2] * 3;
-    vec3 p0 = v3(gload(q0), gload(q0 + 1), gload(q0 + 2)), p1 = v3(gload(q1), gload(q1 + 1), gload(q1 + 2)), p2 = v3(gload(q2), gload(q2 + 1), gload(q2 + 2));
-    uint32_t ts0 = 0, ts1 = 0, ts2 = 0;
+    const PacketVerts pv = load_shade_packet(pk);
+    const vec3 p0 = pv.p[0], p1 = pv.p[1], p2 = pv.p[2];
     const bool has_ts = in.p_tangent_space != nullptr;
-    if (has_ts) { ts0 = gload(in.p_tangent_space + v[0]); ts1 = gload(in.p_tangent_space + v[1]); ts2 = gload(in.p_tangent_space + v[2]); }
-    a.color = fetch_vertex_color(in, v, w);
-    a.tc[0] = fetch_texcoord(in.p_texcoord[0], v, w);
-    a.tc[1] = fetch_texcoord(in.p_texcoord[1], v, w);
+    const uint32_t ts0 = pv.ts[0], ts1 = pv.ts[1], ts2 = pv.ts[2];
+    a.color = fetch_vertex_color(in, pv, w);
+    a.tc[0] = fetch_texcoord(in.p_texcoord[0] != nullptr, pv.uv0, w);
+    a.tc[1] = fetch_texcoord(in.p_texcoord[1] != nullptr, pv.uv1, w);
     vec3 pos = w.x * p0 + w.y * p1 + w.z * p2;
     vec3 ng = cross(p1 - p0, p2 - p0);                     // :196-199 un-normalised
     vec3 n, t;

@@ -36,14 +36,13 @@ struct HitRec { float t, u, v; int tri; bool front; };
 struct LaneStats { unsigned nodes, tris, taps, overflow; };
 
 // Alpha of a candidate hit: AnyHit / ShadowAnyHit (PathTracer.lib.hlsl:1010-1035, 1053-1079).
-PT_DEV void candidate_alpha(const SceneRec& sc, uint32_t inst, uint32_t prim, float u, float v, unsigned& taps, float& base_alpha,
+PT_DEV void candidate_alpha(const SceneRec& sc, uint32_t inst, int tri, float u, float v, unsigned& taps, float& base_alpha,
                             float& alpha, float& cutoff) {
     const InstanceRec& in = sc.instances[inst];
     vec3 w = v3(1 - u - v, u, v);
-    uint32_t vi[3];
-    fetch_indices(in, prim, vi);
-    vec4 c = fetch_vertex_color(in, vi, w);
-    vec2 tc[2] = {fetch_texcoord(in.p_texcoord[0], vi, w), fetch_texcoord(in.p_texcoord[1], vi, w)};
+    const PacketVerts pv = load_shade_packet(sc.shade + tri);
+    vec4 c = fetch_vertex_color(in, pv, w);
+    vec2 tc[2] = {fetch_texcoord(in.p_texcoord[0] != nullptr, pv.uv0, w), fetch_texcoord(in.p_texcoord[1] != nullptr, pv.uv1, w)};
     base_color_alpha(sc, sc.rmats + in.gpu.material_id, tc, c, taps, base_alpha, alpha, cutoff);
 }
 
@@ -179,7 +178,7 @@ PT_DEV void trav_leaf_step(Trav& t, const SceneRec& sc, const int* lds_stack, co
                 bool accept = true;
                 if ((tflags & TF_FORCE_NON_OPAQUE) || (t.rf & RF_FORCE_NON_OPAQUE)) {
                     float base_a, a, cutoff;
-                    candidate_alpha(sc, __float_as_uint(q0.w), __float_as_uint(q1.w), u, v, st.taps, base_a, a, cutoff);
+                    candidate_alpha(sc, __float_as_uint(q0.w), tri, u, v, st.taps, base_a, a, cutoff);
                     if (t.mode == 0) accept = !(base_a < cutoff);                 // IgnoreHit
                     else {
                         t.transmission *= 1 - a;
