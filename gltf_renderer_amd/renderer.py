@@ -36,6 +36,9 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise MiptError("libmipt.so not found at %s: build it with `make -C gltf_renderer_amd/csrc` "
                         "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+    # One HIP runtime per process: PyTorch ships its own libamdhip64, and whichever copy is mapped first serves both.  Import
+    # torch BEFORE libmipt.so so that it is torch's copy (loading /opt/rocm's first makes later device queries fail).
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     missing = [s for s in EXPORTS if not hasattr(L, s)]
     if missing:
