@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0,
                     help="samples per pixel per step (sample batch, pt_set_samples_per_trace); default 8 on one GPU, 8 x N with --scaling weak (max 64)")
     ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"], help="per-frame assembly on rank 0: own-tile gather (default) or full-image reduce")
+    ap.add_argument("--cull-null-shadow", action="store_true", help="experiment: pt_set_null_shadow_culling(1) -- same image, fewer shadow rays than the reference traces (off for the headline line)")
     ap.add_argument("--animate", action="store_true", help="config 5 (--config figure): skin -> BVH rebuild -> trace every step, accumulation reset each frame")
     args = ap.parse_args()
 
@@ -124,6 +125,7 @@ def main():
     if args.animate:
         spp = 1                               # a playing animation resets accumulation every frame (Main.cpp:521-523)
     r.set_samples_per_trace(spp)              # one launch carries the step's samples: a 1/N tile shard still fills the GPU
+    r.set_null_shadow_culling(args.cull_null_shadow)
     out = r.create_output(s.width, s.height)
     torch.cuda.synchronize()
     accel_ms = r.stats().accel_ms
@@ -230,6 +232,7 @@ def main():
                           len(s.instances), len(s.textures), len(s.lights), settings.flags),
                        "parallelism": ("tile-shard x%d + 1 RCCL %s/frame" % (world, "tile gather to rank 0 (point to point)" if exchange["mode"] == "gather" else "reduce(sum)"))
                                       if world > 1 else "single GPU",
+                       "null_shadow_culling": bool(args.cull_null_shadow),
                        "samples_per_step": spp, "ms_per_1spp_frame": round(elapsed / args.steps / spp * 1000.0, 4),
                        "rays_per_frame": round(rays_total / args.steps / spp, 1), "bvh_build_ms": round(accel_ms, 3), "scene_setup_s": round(t_setup, 1)},
         }

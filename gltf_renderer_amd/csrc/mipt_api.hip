@@ -60,6 +60,7 @@ struct pt_ctx {
     bool have_trace = false, have_accel = false, have_skin = false;
     int bounce_limit = PT_REFERENCE_MAX_BOUNCES;
     int samples_per_trace = 1;
+    bool cull_null_shadow = false;
     bool counters_enabled = false;
 
     // ---- Pathtracer cross-frame state (Source/Pathtracer.h:152-153)
@@ -243,6 +244,7 @@ public:
                 const long long room = (long long)settings->max_accumulated_frames - ctx->accumulated_frames;
                 if ((long long)batch > room) batch = (int)room;
             }
+            fc.cull_null_shadow = ctx->cull_null_shadow ? 1u : 0u;
             fc.spp = 1; fc.pixel_slots = fc.my_tiles * 256u;
             fc.seed_step = settings->use_frame_as_seed ? 1u : 0u;
 
@@ -627,6 +629,12 @@ int pt_set_bounce_limit(pt_ctx* ctx, int limit) {
 int pt_set_samples_per_trace(pt_ctx* ctx, int samples) {
     if (!ctx || samples < 1 || samples > PT_MAX_SAMPLES_PER_TRACE) return PT_ERR_INVALID_ARGUMENT;
     ctx->samples_per_trace = samples;
+    return PT_OK;
+}
+
+int pt_set_null_shadow_culling(pt_ctx* ctx, int enable) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    ctx->cull_null_shadow = enable != 0;
     return PT_OK;
 }
 

@@ -168,6 +168,7 @@ struct FrameConstants {
     // Sample batch: one launch carries `spp` samples of every pixel (slot = sample * pixel_slots + pixel slot), equivalent to
     // `spp` consecutive PathtraceScene calls: sample k uses seed + k * seed_step and blends with accumulated_frames + k.
     uint32_t spp, pixel_slots, seed_step;
+    uint32_t cull_null_shadow;       // pt_set_null_shadow_culling: do not trace a shadow ray whose pending term is exactly zero
 };
 
 struct Counters {

@@ -120,7 +120,13 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
             contrib = (mis * f * lcol) / light_pdf;
         }
         if (flags & PT_FLAG_INDIRECT_ENVIRONMENT_ONLY) c += contrib;                                 // TraceShadowRay returns 1 untraced (:726-728)
-        else { fu.q_env = true; fu.pend_env = ps.beta * contrib; fu.env_dir = ldir; }
+        else {
+            fu.pend_env = ps.beta * contrib;
+            // The reference traces this ray before it knows the sample is worth anything (:932).  With null-ray culling on, a
+            // sample whose weighted contribution is exactly (0,0,0) is not traced: T * 0 adds nothing whatever T is (a NaN term is
+            // not zero and is still traced).  Off by default so ray counts match the reference's.
+            if (!(fc.cull_null_shadow && fu.pend_env.x == 0.0f && fu.pend_env.y == 0.0f && fu.pend_env.z == 0.0f)) { fu.q_env = true; fu.env_dir = ldir; }
+        }
     }
     // punctual-light NEE :945-956 (SamplePointLight :680-686)
     if ((flags & PT_FLAG_POINT_LIGHTS) && fc.num_of_lights > 0) {
@@ -136,7 +142,10 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
             vec3 f = evaluate_bsdf(flags, sc.sheen_e, sp, lobes, va.ng, view, ldir, bp);
             contrib = (lcol * f) / pdf;
         }
-        if ((flags & PT_FLAG_SHADOW_RAYS) && !(flags & PT_FLAG_INDIRECT_ENVIRONMENT_ONLY)) { fu.q_light = true; fu.pend_light = ps.beta * contrib; fu.light_dir = ldir; }
+        if ((flags & PT_FLAG_SHADOW_RAYS) && !(flags & PT_FLAG_INDIRECT_ENVIRONMENT_ONLY)) {
+            fu.pend_light = ps.beta * contrib;
+            if (!(fc.cull_null_shadow && fu.pend_light.x == 0.0f && fu.pend_light.y == 0.0f && fu.pend_light.z == 0.0f)) { fu.q_light = true; fu.light_dir = ldir; }
+        }
         else c += contrib;
     }
     fu.add = ps.beta * c;

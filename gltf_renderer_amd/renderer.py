@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmipt.so")
 # every symbol include/mipt.h declares
 EXPORTS = ["pt_abi_version", "pt_create", "pt_destroy", "pt_last_error", "pt_buffer_create", "pt_buffer_update", "pt_buffer_read",
            "pt_texture_create", "pt_sampler_create", "pt_scene_set_materials", "pt_scene_set_lights", "pt_scene_set_instances",
-           "pt_env_create", "pt_env_read", "pt_build_accel", "pt_skin_run", "pt_trace", "pt_set_bounce_limit", "pt_set_samples_per_trace", "pt_enable_counters",
+           "pt_env_create", "pt_env_read", "pt_build_accel", "pt_skin_run", "pt_trace", "pt_set_bounce_limit", "pt_set_samples_per_trace", "pt_set_null_shadow_culling", "pt_enable_counters",
            "pt_set_kernel_mode",
            "pt_get_stats", "pt_reset_stats", "pt_readback", "pt_tonemap"]
 
@@ -66,6 +66,7 @@ def load_library():
     L.pt_trace.argtypes = [vp, vp, vp]
     L.pt_set_bounce_limit.argtypes = [vp, ci]
     L.pt_set_samples_per_trace.argtypes = [vp, ci]
+    L.pt_set_null_shadow_culling.argtypes = [vp, ci]
     L.pt_enable_counters.argtypes = [vp, ci]
     L.pt_set_kernel_mode.argtypes = [vp, ci, ci]
     L.pt_get_stats.argtypes = [vp, vp]
@@ -188,6 +189,10 @@ class Renderer:
     def set_samples_per_trace(self, samples):
         """Sample batch: one trace() then stands for `samples` consecutive frames (bit-identical to issuing them one by one)."""
         self._check(self.L.pt_set_samples_per_trace(self.h, int(samples)))
+
+    def set_null_shadow_culling(self, on):
+        """Skip shadow rays whose contribution is exactly zero (same image, fewer rays than the reference traces)."""
+        self._check(self.L.pt_set_null_shadow_culling(self.h, int(bool(on))))
 
     def enable_counters(self, on):
         self._check(self.L.pt_enable_counters(self.h, int(on)))

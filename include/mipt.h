@@ -370,6 +370,11 @@ int pt_set_bounce_limit(pt_ctx* ctx, int limit);      /* default PT_REFERENCE_MA
  * or with a debug output, the batch is ignored: the call renders the one sample of `frame`, as always.  Default 1. */
 #define PT_MAX_SAMPLES_PER_TRACE 64
 int pt_set_samples_per_trace(pt_ctx* ctx, int samples);
+/* Null shadow rays.  The reference traces every NEE shadow ray before it evaluates the BSDF (PathTracer.lib.hlsl:932, 948), also
+ * when the sample then contributes nothing (light behind the surface, black texel, light out of range).  With culling enabled a
+ * shadow ray whose weighted contribution is exactly (0,0,0) is not traced: the image is unchanged (T * 0 adds nothing), the ray
+ * counts drop.  Default 0, so that rays-per-frame and Mrays/s mean what they mean for the reference. */
+int pt_set_null_shadow_culling(pt_ctx* ctx, int enable);
 int pt_enable_counters(pt_ctx* ctx, int enable);      /* node / triangle / tap counters (slower) */
 /* Kernel arrangement (same per-vertex code, same results up to fp32 accumulation order): PT_MODE_WAVEFRONT (default) =
  * staged trace / shade / shadow kernels over SoA ray queues in HBM with ballot compaction; PT_MODE_MEGAKERNEL = one

@@ -260,6 +260,29 @@ def test_sample_batch_equals_the_same_frames_one_by_one(R, mode):
     r.close()
 
 
+@pytest.mark.parametrize("mode", [abi.MODE_WAVEFRONT, abi.MODE_MEGAKERNEL])
+def test_null_shadow_culling_keeps_the_image_and_drops_rays(R, mode):
+    """pt_set_null_shadow_culling: a shadow ray whose pending term is exactly zero adds T * 0; not tracing it must leave every bit
+    of the image alone, lower rays_shadow and leave primary / bounce counts alone.  Off by default (reference ray counts)."""
+    s = scenes.test_scene(96, 64)           # spot + point + directional lights, env map, alpha-tested and transmissive materials
+    r = R(); h = s.upload(r)
+    r.set_kernel_mode(mode)
+    imgs, rays = [], []
+    for cull in (0, 1, 0):
+        r.set_null_shadow_culling(cull)
+        out = r.create_output(s.width, s.height)
+        st = copy_settings(s.settings); st.reset = 1
+        r.reset_stats()
+        for f in range(3):
+            r.trace(st, s.execute_params(f, env_handle=h["env"]), out); st.reset = 0
+        q = r.stats()
+        imgs.append(r.readback(out)); rays.append((q.rays_primary, q.rays_bounce, q.rays_shadow))
+    assert np.array_equal(imgs[0], imgs[1]) and np.array_equal(imgs[0], imgs[2])
+    assert rays[0] == rays[2]
+    assert rays[1][:2] == rays[0][:2] and rays[1][2] < rays[0][2]
+    r.close()
+
+
 def test_tile_shards_compose_bit_exactly_on_gpu(R):
     s = scenes.test_scene(200, 16)          # 200 = 12.5 tiles: ragged edges
     r = R(); h = s.upload(r)
