@@ -4,11 +4,12 @@
 // The reference keeps one BLAS per primitive and rebuilds a TLAS of <= 1000 instances every frame.
 // Here every instance is flattened into ONE world-space triangle soup and a single BVH2 is built over
 // it (no per-instance ray transform, no overlapping instance boxes to enter):
-//   1. setup     : (instance, primitive) -> world-space 48-B packet, centroid bounds by float atomics
+//   1. setup     : (instance, primitive) -> world-space 48-B packet, centroid bounds per block, then one block folds them
 //   2. morton    : 63-bit Morton code of the centroid (21 bits / axis)
 //   3. sort      : rocPRIM radix sort of (code, triangle id)                       [library primitive]
 //   4. hierarchy : Karras 2012 radix tree, one lane per internal node
-//   5. fit       : bottom-up AABB propagation, second arriver continues (agent-scope acq_rel counter)
+//   5. fit       : a min/max segment tree over the sorted triangles' boxes; every radix-tree node covers a contiguous range
+//                  of them, so its box is one O(log count) range query -- no inter-lane hand-over, no fences
 // Every stage streams its arrays once (HBM-bound; 48 B + 8 B + 64 B per triangle).
 #include <hip/hip_runtime.h>
 #include <cstring>
@@ -29,9 +30,27 @@ __device__ __forceinline__ float sortable_to_float(uint32_t u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
-__global__ void k_init_bounds(uint32_t* b) {
-    if (threadIdx.x < 3) b[threadIdx.x] = 0xffffffffu;
-    else if (threadIdx.x < 6) b[threadIdx.x] = 0u;
+// Folds the per-block centroid bounds k_setup left (6 floats per block) into bounds[6] (sortable uints).  One block.
+__global__ __launch_bounds__(256) void k_bounds(const float* __restrict__ partial, uint32_t n_blocks, uint32_t* __restrict__ bounds) {
+    __shared__ float red[4][6];
+    float v[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += 256) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { v[a] = fminf(v[a], partial[b * 6 + a]); v[3 + a] = fmaxf(v[3 + a], partial[b * 6 + 3 + a]); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { v[a] = fminf(v[a], __shfl_down(v[a], off, 64)); v[3 + a] = fmaxf(v[3 + a], __shfl_down(v[3 + a], off, 64)); }
+    }
+    if ((threadIdx.x & 63) == 0) for (int a = 0; a < 6; a++) red[threadIdx.x >> 6][a] = v[a];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int a = threadIdx.x;
+        float r = red[0][a];
+        for (int w = 1; w < 4; w++) r = a < 3 ? fminf(r, red[w][a]) : fmaxf(r, red[w][a]);
+        bounds[a] = float_to_sortable(r);
+    }
 }
 
 __device__ __forceinline__ uint32_t load_index(const BufferRec* buffers, int desc, uint32_t i) {
@@ -42,7 +61,8 @@ __device__ __forceinline__ uint32_t load_index(const BufferRec* buffers, int des
 
 // 1. one lane per triangle: find its instance (binary search on tri_offset), build the world-space packet.
 __global__ __launch_bounds__(256) void k_setup(const BufferRec* __restrict__ buffers, const InstanceRec* __restrict__ instances, int n_inst,
-                                               uint32_t n_tris, TriPacket* __restrict__ out, uint32_t* __restrict__ bounds) {
+                                               uint32_t n_tris, TriPacket* __restrict__ out, float* __restrict__ block_bounds) {
+    __shared__ float red[4][6];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     vec3 c = v3(0);
     bool valid = i < n_tris;
@@ -70,7 +90,8 @@ __global__ __launch_bounds__(256) void k_setup(const BufferRec* __restrict__ buf
         vec3 mn = hmin(hmin(w[0], w[1]), w[2]), mx = hmax(hmax(w[0], w[1]), w[2]);
         c = (mn + mx) * 0.5f;
     }
-    // wave-level min/max of the centroid, one atomic per wave per component
+    // min/max of the centroid: wave shuffle, then the block's four waves through LDS; one 24-B row per block, folded by k_bounds
+    // (float atomics on six shared words serialise: 280 us for 257 k triangles, against 6 us this way)
     float mnx = valid ? c.x : INFINITY, mny = valid ? c.y : INFINITY, mnz = valid ? c.z : INFINITY;
     float mxx = valid ? c.x : -INFINITY, mxy = valid ? c.y : -INFINITY, mxz = valid ? c.z : -INFINITY;
 #pragma unroll
@@ -78,9 +99,16 @@ __global__ __launch_bounds__(256) void k_setup(const BufferRec* __restrict__ buf
         mnx = fminf(mnx, __shfl_down(mnx, off, 64)); mny = fminf(mny, __shfl_down(mny, off, 64)); mnz = fminf(mnz, __shfl_down(mnz, off, 64));
         mxx = fmaxf(mxx, __shfl_down(mxx, off, 64)); mxy = fmaxf(mxy, __shfl_down(mxy, off, 64)); mxz = fmaxf(mxz, __shfl_down(mxz, off, 64));
     }
-    if ((threadIdx.x & 63) == 0 && mnx <= mxx) {
-        atomicMin(bounds + 0, float_to_sortable(mnx)); atomicMin(bounds + 1, float_to_sortable(mny)); atomicMin(bounds + 2, float_to_sortable(mnz));
-        atomicMax(bounds + 3, float_to_sortable(mxx)); atomicMax(bounds + 4, float_to_sortable(mxy)); atomicMax(bounds + 5, float_to_sortable(mxz));
+    if ((threadIdx.x & 63) == 0) {
+        float* r = red[threadIdx.x >> 6];
+        r[0] = mnx; r[1] = mny; r[2] = mnz; r[3] = mxx; r[4] = mxy; r[5] = mxz;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int a = threadIdx.x;
+        float r = red[0][a];
+        for (int w = 1; w < 4; w++) r = a < 3 ? fminf(r, red[w][a]) : fmaxf(r, red[w][a]);
+        block_bounds[blockIdx.x * 6 + a] = r;
     }
 }
 
@@ -185,35 +213,85 @@ __global__ __launch_bounds__(256) void k_shade_packets(const TriPacket* __restri
     for (int q = 0; q < 8; q++) d[q] = s[q];
 }
 
-// 5. bottom-up fit.  parent codes are node*2 + slot.
-__global__ __launch_bounds__(256) void k_fit(const TriPacket* __restrict__ tris, uint32_t n, BvhNode* nodes, const int32_t* __restrict__ node_parent,
-                                             const int32_t* __restrict__ leaf_parent, uint32_t* flags) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const TriPacket& t = tris[i];
-    vec3 a = v3p(t.v0), b = a + v3p(t.e1), c = a + v3p(t.e2);
-    vec3 lo = hmin(hmin(a, b), c), hi = hmax(hmax(a, b), c);
-    int code = leaf_parent[i];
-    while (code >= 0) {
-        int p = code >> 1, slot = code & 1;
-        float* dst = slot ? nodes[p].lo1 : nodes[p].lo0;     // lo then hi are contiguous (6 floats)
-        __hip_atomic_store(dst + 0, lo.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 1, lo.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 2, lo.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 3, hi.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 4, hi.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 5, hi.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // release my box, acquire the sibling's: the second arriver at a node continues upwards
-        uint32_t old = __hip_atomic_fetch_add(flags + p, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == 0) return;
-        const float* src = slot ? nodes[p].lo0 : nodes[p].lo1;
-        vec3 slo = v3(__hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                      __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        vec3 shi = v3(__hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(src + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                      __hip_atomic_load(src + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        lo = hmin(lo, slo); hi = hmax(hi, shi);
-        code = node_parent[p];
+// 5. fit.  A radix-tree node covers a contiguous range [first, first + count) of the sorted triangles (k_hierarchy left it in
+//    _pad), so its box is a range min/max over their boxes.  T is a heap-ordered segment tree over P (a power of two >= n)
+//    leaf slots: T[P + i] = box of triangle i, T[k] = T[2k] U T[2k+1], root T[1].  It is built eight levels per launch through
+//    LDS; a query unites O(log count) nodes.  min/max are exact, so the boxes are those of any other summation order.
+//    (The textbook alternative -- lanes climb from the leaves and the second arriver at a node carries on -- needs an
+//    agent-scope release/acquire pair per level, which on eight XCDs with separate L2s costs an L2 write-back and invalidate each
+//    time: 700 us for 257 k triangles, against ~35 us for the tree and the queries.)
+struct __attribute__((aligned(16))) SegBox { float lo[3], _a, hi[3], _b; };
+static_assert(sizeof(SegBox) == 32, "SegBox");
+
+// One pass: each block takes 256 consecutive entries of the input level (heap indices in_base + e; in_base is a power of two and
+// equals that level's size) and writes the eight levels above them.  LEAVES: the input entries are the triangles' boxes, computed
+// here and stored as level P; otherwise they are read back from T.  Entries >= in_valid count as empty.
+template <bool LEAVES>
+__global__ __launch_bounds__(256) void k_seg_pass(const TriPacket* __restrict__ tris, SegBox* __restrict__ T, uint32_t in_base, uint32_t in_valid) {
+    __shared__ float sh[6][256];
+    const uint32_t t = threadIdx.x, e = blockIdx.x * 256u + t;
+    float b[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (e < in_valid) {
+        if (LEAVES) {
+            const TriPacket& tp = tris[e];
+            const vec3 p = v3p(tp.v0), q = p + v3p(tp.e1), r = p + v3p(tp.e2);
+            const vec3 lo = hmin(hmin(p, q), r), hi = hmax(hmax(p, q), r);
+            b[0] = lo.x; b[1] = lo.y; b[2] = lo.z; b[3] = hi.x; b[4] = hi.y; b[5] = hi.z;
+            SegBox o; o.lo[0] = b[0]; o.lo[1] = b[1]; o.lo[2] = b[2]; o._a = 0; o.hi[0] = b[3]; o.hi[1] = b[4]; o.hi[2] = b[5]; o._b = 0;
+            T[in_base + e] = o;
+        } else {
+            const SegBox& s = T[in_base + e];
+            b[0] = s.lo[0]; b[1] = s.lo[1]; b[2] = s.lo[2]; b[3] = s.hi[0]; b[4] = s.hi[1]; b[5] = s.hi[2];
+        }
     }
+#pragma unroll
+    for (int a = 0; a < 6; a++) sh[a][t] = b[a];
+    __syncthreads();
+    for (int k = 1; k <= 8; k++) {
+        const bool act = t < (256u >> k);
+        if (act) {
+#pragma unroll
+            for (int a = 0; a < 3; a++) { b[a] = fminf(sh[a][2 * t], sh[a][2 * t + 1]); b[3 + a] = fmaxf(sh[3 + a][2 * t], sh[3 + a][2 * t + 1]); }
+        }
+        __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int a = 0; a < 6; a++) sh[a][t] = b[a];
+            // entry (blockIdx*256 + (t << k)) of the input level folds into entry >> k of the level k above
+            if ((in_base >> k) != 0 && blockIdx.x * 256u + (t << k) < in_base) {
+                SegBox o; o.lo[0] = b[0]; o.lo[1] = b[1]; o.lo[2] = b[2]; o._a = 0; o.hi[0] = b[3]; o.hi[1] = b[4]; o.hi[2] = b[5]; o._b = 0;
+                T[(in_base >> k) + ((blockIdx.x * 256u) >> k) + t] = o;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void seg_query(const SegBox* __restrict__ T, uint32_t P, uint32_t first, uint32_t count, float* lo, float* hi) {
+    float b[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    auto take = [&](uint32_t k) {
+        const SegBox& s = T[k];
+#pragma unroll
+        for (int a = 0; a < 3; a++) { b[a] = fminf(b[a], s.lo[a]); b[3 + a] = fmaxf(b[3 + a], s.hi[a]); }
+    };
+    for (uint32_t l = first + P, r = first + count + P; l < r; l >>= 1, r >>= 1) {
+        if (l & 1u) take(l++);
+        if (r & 1u) take(--r);
+    }
+    lo[0] = b[0]; lo[1] = b[1]; lo[2] = b[2]; hi[0] = b[3]; hi[1] = b[4]; hi[2] = b[5];
+}
+
+// one lane per radix-tree node: the boxes of its two children
+__global__ __launch_bounds__(256) void k_fit(const SegBox* __restrict__ T, uint32_t P, uint32_t n_nodes, BvhNode* __restrict__ nodes) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    BvhNode& n = nodes[i];
+    const int32_t c0 = n.child0, c1 = n.child1;
+    uint32_t f0, k0, f1, k1;
+    if (c0 < 0) { f0 = (uint32_t)~c0; k0 = 1; } else { f0 = nodes[c0]._pad[0]; k0 = nodes[c0]._pad[1]; }
+    if (c1 < 0) { f1 = (uint32_t)~c1; k1 = 1; } else { f1 = nodes[c1]._pad[0]; k1 = nodes[c1]._pad[1]; }
+    seg_query(T, P, f0, k0, n.lo0, n.hi0);
+    seg_query(T, P, f1, k1, n.lo1, n.hi1);
 }
 
 // 6. collapse to 4-wide.  Binary nodes at even depth are kept; each gathers its (up to 4) grandchildren, whose boxes are
@@ -264,15 +342,23 @@ __global__ __launch_bounds__(256) void k_collapse(const BvhNode* __restrict__ no
 #endif
 constexpr bool kGreedyCollapse = PT_GREEDY_COLLAPSE != 0;
 
+constexpr int kCollapseMaxLevels = 4096;
+__global__ __launch_bounds__(256) void k_collapse_init(uint32_t* __restrict__ frontier, uint32_t* __restrict__ widx, uint32_t* __restrict__ counters) {
+    for (int k = threadIdx.x; k < kCollapseMaxLevels + 16; k += 256) counters[k] = k <= 1 ? 1u : 0u;   // one wide node (the root), level 0 holds one entry
+    if (threadIdx.x == 0) { frontier[0] = 0u; widx[0] = 0u; }                                       // binary node 0 -> wide node 0
+}
+
 // 6'. collapse to 4-wide, greedily by surface area (one launch per level of the WIDE tree, top down).  A frontier entry is a
 //     binary node that becomes a wide node; it starts with its two children and keeps opening the inner child with the largest
 //     box until it holds four children or only leaves.  Compared with "keep every even level" this fills the slots (about 3.0 ->
 //     3.6 children per node on the Sponza-class scene), so the tree is shallower and a ray visits fewer nodes.
 __global__ __launch_bounds__(256) void k_collapse_level(const BvhNode* __restrict__ nodes2, const uint32_t* __restrict__ frontier_in,
-                                                        const uint32_t* __restrict__ widx_in, uint32_t n_in, uint32_t* __restrict__ frontier_out,
+                                                        const uint32_t* __restrict__ widx_in, uint32_t level, uint32_t* __restrict__ frontier_out,
                                                         uint32_t* __restrict__ widx_out, uint32_t* __restrict__ counters, Bvh4Node* __restrict__ out) {
+    // counters[0]: wide nodes allocated so far; counters[1 + L]: size of level L's frontier.  The host launches several levels
+    // without looking (grids sized for the largest frontier the level can have), so a level may well be empty.
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_in) return;
+    if (i >= counters[1 + level]) return;
     // an inner subtree of at most kLeafMax triangles becomes ONE leaf reference (its triangles are contiguous): the bottom of a
     // binary tree is full of 2- and 3-triangle subtrees, which as wide nodes would spend a whole node step on two boxes
     auto child_ref = [&](int32_t r) -> int32_t {
@@ -300,15 +386,33 @@ __global__ __launch_bounds__(256) void k_collapse_level(const BvhNode* __restric
         for (int a = 0; a < 3; a++) { lo[pick][a] = m.lo0[a]; hi[pick][a] = m.hi0[a]; lo[cnt][a] = m.lo1[a]; hi[cnt][a] = m.hi1[a]; }
         cnt++;
     }
+    // children that stay inner nodes become wide nodes of the next level: one pair of atomics per wave reserves their frontier
+    // slots and wide-node indices (the two advance together)
+    uint32_t mine = 0;
+    for (int k = 0; k < cnt; k++) mine += ref[k] >= 0 ? 1u : 0u;
+    uint32_t incl = mine;
+    const uint32_t lane = __lane_id();
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off, 64);
+        if (lane >= (uint32_t)off) incl += up;
+    }
+    const unsigned long long active = __ballot(1);
+    const int last = 63 - __clzll((long long)active), leader = __ffsll((long long)active) - 1;
+    const uint32_t total = __shfl(incl, last, 64);
+    uint32_t base_f = 0, base_w = 0;
+    if ((int)lane == leader && total) { base_f = atomicAdd(counters + 2 + level, total); base_w = atomicAdd(counters + 0, total); }
+    base_f = __shfl(base_f, leader, 64); base_w = __shfl(base_w, leader, 64);
+    uint32_t slot = incl - mine;
     Bvh4Node w;
     for (int k = 0; k < 4; k++) {
         if (k < cnt) {
             int32_t r = ref[k];
-            if (r >= 0) {                                             // stays an inner node: becomes a wide node of the next level
-                const uint32_t wi = atomicAdd(counters + 1, 1u), pos = atomicAdd(counters + 0, 1u);
-                frontier_out[pos] = (uint32_t)r;
-                widx_out[pos] = wi;
-                r = (int32_t)wi;
+            if (r >= 0) {
+                frontier_out[base_f + slot] = (uint32_t)r;
+                widx_out[base_f + slot] = base_w + slot;
+                r = (int32_t)(base_w + slot);
+                slot++;
             }
             wide_set(w, k, lo[k], hi[k], r);
         } else {
@@ -325,7 +429,7 @@ __global__ __launch_bounds__(256) void k_collapse_level(const BvhNode* __restric
 
 static void free_all(AccelScratch& s) {
     hipFree(s.tris_unsorted); hipFree(s.keys_a); hipFree(s.keys_b); hipFree(s.vals_a); hipFree(s.vals_b);
-    hipFree(s.leaf_parent); hipFree(s.node_parent); hipFree(s.flags); hipFree(s.sort_temp);
+    hipFree(s.leaf_parent); hipFree(s.node_parent); hipFree(s.seg); hipFree(s.block_bounds); hipFree(s.sort_temp);
     hipFree(s.nodes2); hipFree(s.kept); hipFree(s.widx); hipFree(s.scan_temp); hipFree(s.collapse_counters);
 }
 
@@ -344,7 +448,10 @@ static hipError_t ensure(AccelScratch& s, size_t n) {
     if ((e = hipMalloc(&s.vals_b, cap * 4))) return e;
     if ((e = hipMalloc(&s.leaf_parent, cap * 4))) return e;
     if ((e = hipMalloc(&s.node_parent, cap * 4))) return e;
-    if ((e = hipMalloc(&s.flags, cap * 4))) return e;
+    s.seg_leaves = 256;
+    while (s.seg_leaves < cap) s.seg_leaves <<= 1;
+    if ((e = hipMalloc(&s.seg, 2 * s.seg_leaves * 32))) return e;
+    if ((e = hipMalloc(&s.block_bounds, (cap / 256 + 2) * 6 * sizeof(float)))) return e;
     if ((e = hipMalloc(&s.nodes2, cap * sizeof(BvhNode)))) return e;
     if ((e = hipMalloc(&s.kept, (cap + 1) * 4))) return e;
     if ((e = hipMalloc(&s.widx, (cap + 1) * 4))) return e;
@@ -357,7 +464,7 @@ static hipError_t ensure(AccelScratch& s, size_t n) {
     if ((e = rocprim::exclusive_scan(nullptr, sb, s.kept, s.widx, 0u, cap + 1, rocprim::plus<uint32_t>(), (hipStream_t)0))) return e;
     if ((e = hipMalloc(&s.scan_temp, sb))) return e;
     s.scan_temp_bytes = sb;
-    if ((e = hipMalloc(&s.collapse_counters, 16))) return e;
+    if ((e = hipMalloc(&s.collapse_counters, (kCollapseMaxLevels + 16) * 4))) return e;
     s.capacity = cap;
     return hipSuccess;
 }
@@ -376,8 +483,8 @@ hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const Instan
     hipError_t e = ensure(s, n_tris);
     if (e) return e;
     const uint32_t g = (n_tris + 255) / 256;
-    hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, stream, s.bounds);
-    hipLaunchKernelGGL(k_setup, dim3(g), dim3(256), 0, stream, d_buffers, d_instances, n_inst, n_tris, s.tris_unsorted, s.bounds);
+    hipLaunchKernelGGL(k_setup, dim3(g), dim3(256), 0, stream, d_buffers, d_instances, n_inst, n_tris, s.tris_unsorted, s.block_bounds);
+    hipLaunchKernelGGL(k_bounds, dim3(1), dim3(256), 0, stream, s.block_bounds, g, s.bounds);
     if (n_tris == 1) {
         *root_out = ~0;
         if ((e = hipMemcpyAsync(d_tris, s.tris_unsorted, sizeof(TriPacket), hipMemcpyDeviceToDevice, stream))) return e;
@@ -389,10 +496,19 @@ hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const Instan
     if ((e = rocprim::radix_sort_pairs(s.sort_temp, tb, s.keys_a, s.keys_b, s.vals_a, s.vals_b, (size_t)n_tris, 0, 63, stream))) return e;
     hipLaunchKernelGGL(k_reorder, dim3(g), dim3(256), 0, stream, s.tris_unsorted, s.vals_b, n_tris, d_tris);
     hipLaunchKernelGGL(k_shade_packets, dim3(g), dim3(256), 0, stream, d_tris, n_tris, d_instances, d_shade);
-    if ((e = hipMemsetAsync(s.flags, 0, (size_t)n_tris * 4, stream))) return e;
     hipLaunchKernelGGL(k_hierarchy, dim3(g), dim3(256), 0, stream, s.keys_b, (int)n_tris, s.nodes2, s.node_parent, s.leaf_parent);
-    hipLaunchKernelGGL(k_fit, dim3(g), dim3(256), 0, stream, d_tris, n_tris, s.nodes2, s.node_parent, s.leaf_parent, s.flags);
     const uint32_t n_nodes = n_tris - 1;
+    {
+        SegBox* T = (SegBox*)s.seg;
+        const uint32_t P = (uint32_t)s.seg_leaves;
+        hipLaunchKernelGGL(k_seg_pass<true>, dim3(g), dim3(256), 0, stream, d_tris, T, P, n_tris);
+        uint32_t valid = g;                                          // entries of the level eight above that were written
+        for (uint32_t base = P >> 8; base > 1; base >>= 8) {         // (a pass that starts at level `base` ends at the root or 8 levels up)
+            hipLaunchKernelGGL(k_seg_pass<false>, dim3((valid + 255) / 256), dim3(256), 0, stream, (const TriPacket*)nullptr, T, base, valid);
+            valid = (valid + 255) / 256;
+        }
+        hipLaunchKernelGGL(k_fit, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, T, P, n_nodes, s.nodes2);
+    }
     if (!kGreedyCollapse) {
         hipLaunchKernelGGL(k_mark_kept, dim3(g), dim3(256), 0, stream, s.node_parent, n_nodes, s.kept);
         if ((e = hipMemsetAsync(s.kept + n_nodes, 0, 4, stream))) return e;            // sentinel: widx[n_nodes] = total kept
@@ -406,23 +522,24 @@ hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const Instan
     // greedy collapse, level by level: frontier = binary nodes that become wide nodes, with the wide index their parent gave them
     uint32_t* fr[2] = {s.kept, s.vals_a};
     uint32_t* wi[2] = {s.widx, s.vals_b};                            // (the sort's value buffers are free again by now)
-    const uint32_t first[2] = {0u, 0u};                              // root: binary node 0 -> wide node 0
-    if ((e = hipMemcpyAsync(fr[0], &first[0], 4, hipMemcpyHostToDevice, stream))) return e;
-    if ((e = hipMemcpyAsync(wi[0], &first[1], 4, hipMemcpyHostToDevice, stream))) return e;
-    const uint32_t init[2] = {0u, 1u};                               // [0] next frontier size, [1] wide nodes allocated so far
-    if ((e = hipMemcpyAsync(s.collapse_counters, init, 8, hipMemcpyHostToDevice, stream))) return e;
-    uint32_t count = 1;
-    for (int level = 0, cur = 0; count > 0; level++, cur ^= 1) {
-        if (level > 4096) return hipErrorUnknown;                    // a tree cannot be deeper than its node count allows; guards a hang
-        hipLaunchKernelGGL(k_collapse_level, dim3((count + 255) / 256), dim3(256), 0, stream, s.nodes2, fr[cur], wi[cur], count, fr[cur ^ 1], wi[cur ^ 1],
-                           s.collapse_counters, d_nodes);
-        uint32_t c[2];
-        if ((e = hipMemcpyAsync(c, s.collapse_counters, 8, hipMemcpyDeviceToHost, stream))) return e;
+    hipLaunchKernelGGL(k_collapse_init, dim3(1), dim3(256), 0, stream, fr[0], wi[0], s.collapse_counters);
+    // Levels are launched eight at a time with grids sized for the largest frontier each can have (four times the one before,
+    // at most every node); the kernels read the true sizes from the device, the host looks once per eight levels.
+    uint32_t bound = 1;
+    for (uint32_t level = 0, cur = 0;;) {
+        if (level >= (uint32_t)kCollapseMaxLevels) return hipErrorUnknown;   // far deeper than a 64-bit radix tree can be; guards a hang
+        for (int j = 0; j < 8; j++, level++, cur ^= 1u) {
+            hipLaunchKernelGGL(k_collapse_level, dim3((bound + 255) / 256), dim3(256), 0, stream, s.nodes2, fr[cur], wi[cur], level, fr[cur ^ 1u], wi[cur ^ 1u],
+                               s.collapse_counters, d_nodes);
+            bound = bound > n_nodes / 4 ? n_nodes : bound * 4;
+        }
+        uint32_t next = 0;
+        if ((e = hipMemcpyAsync(&next, s.collapse_counters + 1 + level, 4, hipMemcpyDeviceToHost, stream))) return e;
+        if ((e = hipMemcpyAsync(wide_nodes_out, s.collapse_counters, 4, hipMemcpyDeviceToHost, stream))) return e;
         if ((e = hipStreamSynchronize(stream))) return e;
-        count = c[0];
-        *wide_nodes_out = c[1];
-        if (count > n_nodes) return hipErrorUnknown;
-        if ((e = hipMemsetAsync(s.collapse_counters, 0, 4, stream))) return e;
+        if (next > n_nodes) return hipErrorUnknown;
+        if (next == 0) break;
+        bound = next;
     }
     return hipGetLastError();
 }

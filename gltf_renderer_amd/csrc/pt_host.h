@@ -13,7 +13,9 @@ struct AccelScratch {
     uint32_t *vals_a = nullptr, *vals_b = nullptr;
     int32_t* leaf_parent = nullptr;
     int32_t* node_parent = nullptr;
-    uint32_t* flags = nullptr;
+    void* seg = nullptr;             // min/max segment tree over the sorted triangles' boxes (2 * seg_leaves entries of 32 B)
+    size_t seg_leaves = 0;           // power of two >= capacity
+    float* block_bounds = nullptr;   // k_setup's per-block centroid bounds
     uint32_t* bounds = nullptr;      // 6 sortable-uint floats: min xyz, max xyz
     void* sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
@@ -22,7 +24,7 @@ struct AccelScratch {
     uint32_t* widx = nullptr;        // exclusive scan of kept = wide node index
     void* scan_temp = nullptr;
     size_t scan_temp_bytes = 0;
-    uint32_t* collapse_counters = nullptr;   // greedy collapse: [0] next frontier size, [1] wide nodes allocated
+    uint32_t* collapse_counters = nullptr;   // greedy collapse: [0] wide nodes allocated, [1 + L] frontier size of level L
     size_t capacity = 0;
 };
 void accel_scratch_free(AccelScratch& s);
