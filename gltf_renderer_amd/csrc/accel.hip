@@ -294,8 +294,8 @@ __global__ __launch_bounds__(256) void k_fit(const SegBox* __restrict__ T, uint3
     seg_query(T, P, f1, k1, n.lo1, n.hi1);
 }
 
-// 6. collapse to 4-wide.  Binary nodes at even depth are kept; each gathers its (up to 4) grandchildren, whose boxes are
-//    already stored in the intermediate (odd-depth) nodes.
+// 6. collapse to 4-wide (PT_GREEDY_COLLAPSE=0 variant).  Binary nodes at even depth are kept; each gathers its (up to 4)
+//    grandchildren, whose boxes are already stored in the intermediate (odd-depth) nodes.
 __global__ __launch_bounds__(256) void k_mark_kept(const int32_t* __restrict__ node_parent, uint32_t n_nodes, uint32_t* __restrict__ kept) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
@@ -305,8 +305,35 @@ __global__ __launch_bounds__(256) void k_mark_kept(const int32_t* __restrict__ n
     kept[i] = (depth & 1u) ? 0u : 1u;
 }
 
-__device__ __forceinline__ void wide_set(Bvh4Node& w, int k, const float* lo, const float* hi, int32_t ref) {
-    w.lox[k] = lo[0]; w.loy[k] = lo[1]; w.loz[k] = lo[2]; w.hix[k] = hi[0]; w.hiy[k] = hi[1]; w.hiz[k] = hi[2]; w.child[k] = ref;
+// Writes one 64-B wide node: the children's boxes on the 8-bit grid of the node's own box (pt_types.h Bvh4Node).  Conservative:
+// every lo is rounded down and every hi up, and each is checked against bvh_dequant, the expression the traversal evaluates.
+__device__ void wide_write(Bvh4Node* dst, const float (*lo)[3], const float (*hi)[3], const int32_t* ref, int cnt) {
+    uint32_t word[16];
+    uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0}, exps = 0;
+    for (int a = 0; a < 3; a++) {
+        float p = lo[0][a], top = hi[0][a];
+        for (int k = 1; k < cnt; k++) { p = fminf(p, lo[k][a]); top = fmaxf(top, hi[k][a]); }
+        // smallest power-of-two step whose 255th plane reaches the far side
+        uint32_t e = (__float_as_uint((top - p) * (1.0f / 255.0f)) >> 23) & 0xffu;
+        e = e < 1u ? 1u : (e > 254u ? 254u : e);
+        while (e < 254u && !(bvh_dequant(255u, bvh_step(e), p) >= top)) e++;
+        const float step = bvh_step(e), inv_step = bvh_step(254u - e);
+        for (int k = 0; k < cnt; k++) {
+            int ql = (int)floorf((lo[k][a] - p) * inv_step), qh = (int)ceilf((hi[k][a] - p) * inv_step);
+            ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql); qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
+            while (ql > 0 && bvh_dequant((uint32_t)ql, step, p) > lo[k][a]) ql--;
+            while (qh < 255 && bvh_dequant((uint32_t)qh, step, p) < hi[k][a]) qh++;
+            qlo[a] |= (uint32_t)ql << (8 * k); qhi[a] |= (uint32_t)qh << (8 * k);
+        }
+        word[a] = __float_as_uint(p);
+        exps |= e << (8 * a);
+    }
+    word[3] = exps;
+    for (int k = 0; k < 4; k++) word[4 + k] = (uint32_t)(k < cnt ? ref[k] : kEmptyChild);
+    word[8] = qlo[0]; word[9] = qhi[0]; word[10] = qlo[1]; word[11] = qhi[1]; word[12] = qlo[2]; word[13] = qhi[2]; word[14] = word[15] = 0;
+    uint4* d = (uint4*)dst;
+#pragma unroll
+    for (int q = 0; q < 4; q++) d[q] = make_uint4(word[4 * q], word[4 * q + 1], word[4 * q + 2], word[4 * q + 3]);
 }
 
 __global__ __launch_bounds__(256) void k_collapse(const BvhNode* __restrict__ nodes2, uint32_t n_nodes, const uint32_t* __restrict__ kept,
@@ -314,27 +341,21 @@ __global__ __launch_bounds__(256) void k_collapse(const BvhNode* __restrict__ no
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes || !kept[i]) return;
     const BvhNode& n = nodes2[i];
-    Bvh4Node w;
+    float lo[4][3], hi[4][3];
+    int32_t ref[4];
     int k = 0;
+    auto put = [&](const float* l, const float* h, int32_t r) { for (int a = 0; a < 3; a++) { lo[k][a] = l[a]; hi[k][a] = h[a]; } ref[k] = r; k++; };
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         const int32_t ch = c ? n.child1 : n.child0;
-        const float* lo = c ? n.lo1 : n.lo0;
-        const float* hi = c ? n.hi1 : n.hi0;
-        if (ch < 0) wide_set(w, k++, lo, hi, ch);                      // leaf child stays a leaf
+        if (ch < 0) put(c ? n.lo1 : n.lo0, c ? n.hi1 : n.hi0, ch);     // leaf child stays a leaf
         else {                                                         // odd-depth inner node: adopt its two children
             const BvhNode& m = nodes2[ch];
-            wide_set(w, k++, m.lo0, m.hi0, m.child0 < 0 ? m.child0 : (int32_t)widx[m.child0]);
-            wide_set(w, k++, m.lo1, m.hi1, m.child1 < 0 ? m.child1 : (int32_t)widx[m.child1]);
+            put(m.lo0, m.hi0, m.child0 < 0 ? m.child0 : (int32_t)widx[m.child0]);
+            put(m.lo1, m.hi1, m.child1 < 0 ? m.child1 : (int32_t)widx[m.child1]);
         }
     }
-    const float pinf[3] = {INFINITY, INFINITY, INFINITY}, ninf[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (; k < 4; k++) wide_set(w, k, pinf, ninf, kEmptyChild);
-    w._pad[0] = w._pad[1] = w._pad[2] = w._pad[3] = 0;
-    const float4* src = (const float4*)&w;
-    float4* dst = (float4*)(out + widx[i]);
-#pragma unroll
-    for (int q = 0; q < 8; q++) dst[q] = src[q];
+    wide_write(out + widx[i], lo, hi, ref, k);
 }
 
 #ifndef PT_GREEDY_COLLAPSE
@@ -404,27 +425,15 @@ __global__ __launch_bounds__(256) void k_collapse_level(const BvhNode* __restric
     if ((int)lane == leader && total) { base_f = atomicAdd(counters + 2 + level, total); base_w = atomicAdd(counters + 0, total); }
     base_f = __shfl(base_f, leader, 64); base_w = __shfl(base_w, leader, 64);
     uint32_t slot = incl - mine;
-    Bvh4Node w;
-    for (int k = 0; k < 4; k++) {
-        if (k < cnt) {
-            int32_t r = ref[k];
-            if (r >= 0) {
-                frontier_out[base_f + slot] = (uint32_t)r;
-                widx_out[base_f + slot] = base_w + slot;
-                r = (int32_t)(base_w + slot);
-                slot++;
-            }
-            wide_set(w, k, lo[k], hi[k], r);
-        } else {
-            const float pinf[3] = {INFINITY, INFINITY, INFINITY}, ninf[3] = {-INFINITY, -INFINITY, -INFINITY};
-            wide_set(w, k, pinf, ninf, kEmptyChild);
+    for (int k = 0; k < cnt; k++) {
+        if (ref[k] >= 0) {
+            frontier_out[base_f + slot] = (uint32_t)ref[k];
+            widx_out[base_f + slot] = base_w + slot;
+            ref[k] = (int32_t)(base_w + slot);
+            slot++;
         }
     }
-    w._pad[0] = w._pad[1] = w._pad[2] = w._pad[3] = 0;
-    const float4* src = (const float4*)&w;
-    float4* dst = (float4*)(out + widx_in[i]);
-#pragma unroll
-    for (int q = 0; q < 8; q++) dst[q] = src[q];
+    wide_write(out + widx_in[i], lo, hi, ref, cnt);
 }
 
 static void free_all(AccelScratch& s) {

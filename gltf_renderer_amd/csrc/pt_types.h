@@ -81,16 +81,27 @@ struct __attribute__((aligned(64))) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode");
 
-// 128-B 4-wide node (two 64-B lines, SoA per axis so one dwordx4 load feeds four slab tests): built by collapsing
-// every other level of the LBVH.  child >= 0: wide node index; child < 0: leaf ~triangle index; kEmptyChild: unused
-// slot (its box is lo = +inf, hi = -inf and can never be hit).
-struct __attribute__((aligned(128))) Bvh4Node {
-    float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+// 64-B 4-wide node, the children's boxes quantised to 8 bits per plane on the grid origin + q * 2^(exp - 127) spanned by the
+// node's own box (three dwordx4 + one dwordx2 load per node step instead of seven dwordx4: the traversal stages are bound by
+// vector-memory instruction issue, not by VALU, so the dequantisation is free and the loads saved are time saved).
+// Quantisation is conservative (lo rounded down, hi rounded up, checked with the very fma the traversal uses), so a ray enters a
+// superset of the children it would enter with exact boxes and finds the same hits.
+// child >= 0: wide node index; child < 0: leaf reference (below); kEmptyChild: unused slot (never entered).
+struct __attribute__((aligned(64))) Bvh4Node {
+    float origin[3];                // lo corner of the union of the children
+    uint8_t exp[3], _e;             // biased exponents of the per-axis grid step
     int32_t child[4];
-    uint32_t _pad[4];
+    uint8_t qlox[4], qhix[4], qloy[4], qhiy[4];     // byte k of each word = child k (v_cvt_f32_ubyte<k>)
+    uint8_t qloz[4], qhiz[4];
+    uint32_t _pad[2];
 };
-static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node");
+static_assert(sizeof(Bvh4Node) == 64, "Bvh4Node");
 constexpr int32_t kEmptyChild = 0x7fffffff;
+// the plane a quantised coordinate stands for; build and traversal must use this one expression
+__host__ __device__ __forceinline__ float bvh_dequant(uint32_t q, float step, float origin) { return __builtin_fmaf((float)q, step, origin); }
+__host__ __device__ __forceinline__ float bvh_step(uint32_t biased_exp) {
+    union { uint32_t u; float f; } c; c.u = biased_exp << 23; return c.f;
+}
 // Leaf reference: ~(first | (count - 1) << 28): `count` (1..kLeafMax) triangle packets starting at `first`, contiguous because
 // an LBVH subtree covers a contiguous range of the Morton-sorted triangles.  first < 2^28.
 #ifndef PT_LEAF_MAX
