@@ -207,6 +207,7 @@ __global__ __launch_bounds__(256) void k_shade_packets(const TriPacket* __restri
         if (in.p_texcoord[1]) { float2 t = in.p_texcoord[1][v]; o.uv1[0] = t.x; o.uv1[1] = t.y; }
         if (in.p_color) { uint2 c = in.p_color[v]; o.color[0] = c.x; o.color[1] = c.y; }
     }
+    p.inst = tris[i].inst;
     const float4* s = (const float4*)&p;
     float4* d = (float4*)(out + i);
 #pragma unroll

@@ -167,7 +167,7 @@ PT_DEV vec4 sample_slot(const SceneRec& sc, const RMat* m, int slot, const vec2 
 
 // ---------------------------------------------------------------- vertex fetch (PathTracer.lib.hlsl:176-302)
 // The three vertices of a hit triangle from its 128-B shading packet (pt_types.h ShadePacket: one cache line, 8 x dwordx4).
-struct PacketVerts { vec3 p[3]; uint32_t ts[3]; float2 uv0[3], uv1[3]; uint2 col[3]; };
+struct PacketVerts { vec3 p[3]; uint32_t ts[3]; float2 uv0[3], uv1[3]; uint2 col[3]; uint32_t inst; };
 PT_DEV PacketVerts load_shade_packet(const ShadePacket* pk) {
     const float4* q = (const float4*)pk;
     const float4 r[8] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]};
@@ -182,6 +182,7 @@ PT_DEV PacketVerts load_shade_packet(const ShadePacket* pk) {
         o.uv1[k] = make_float2(f(b + 6), f(b + 7));
         o.col[k] = make_uint2(__float_as_uint(f(b + 8)), __float_as_uint(f(b + 9)));
     }
+    o.inst = __float_as_uint(f(30));
     return o;
 }
 PT_DEV vec4 fetch_vertex_color(const InstanceRec& in, const PacketVerts& pv, vec3 w) {                // :229-242
@@ -201,9 +202,8 @@ struct HitGeom {                       // VertexAttributes, PathTracer.lib.hlsl:
     vec4 color;
     vec2 tc[2];
 };
-PT_DEV HitGeom get_vertex_attributes(const InstanceRec& in, const ShadePacket* pk, vec3 w) {         // :280-302
+PT_DEV HitGeom get_vertex_attributes(const InstanceRec& in, const PacketVerts& pv, vec3 w) {        // :280-302
     HitGeom a;
-    const PacketVerts pv = load_shade_packet(pk);
     const vec3 p0 = pv.p[0], p1 = pv.p[1], p2 = pv.p[2];
     const bool has_ts = in.p_tangent_space != nullptr;
     const uint32_t ts0 = pv.ts[0], ts1 = pv.ts[1], ts2 = pv.ts[2];

@@ -124,7 +124,7 @@ static_assert(sizeof(TriPacket) == 48, "TriPacket");
 // Absent streams hold zeros; which streams exist is still told by the instance row's stream pointers.
 struct __attribute__((aligned(128))) ShadePacket {
     struct V { float pos[3]; uint32_t tangent_space; float uv0[2], uv1[2]; uint32_t color[2]; } v[3];   // 40 B each (object space)
-    uint32_t _pad[2];
+    uint32_t inst, _pad;            // instance-table row (copy of TriPacket::inst: the shade stage never touches the TriPacket)
 };
 static_assert(sizeof(ShadePacket) == 128, "ShadePacket");
 

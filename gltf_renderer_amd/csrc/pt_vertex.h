@@ -47,12 +47,11 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
     const uint32_t flags = fc.flags;
     fu.add = v3(0); fu.overwrite = false; fu.counted_shadow = 0;
     fu.q_env = fu.q_light = fu.q_bounce = false;
-    const float4* tp = (const float4*)sc.tris + (size_t)hit.tri * 3;
-    const uint32_t inst_id = __float_as_uint(tp[0].w), prim = __float_as_uint(tp[1].w);
-    const InstanceRec& inst = sc.instances[inst_id];
+    const PacketVerts pv = load_shade_packet(sc.shade + hit.tri);     // one 128-B line: the three vertices and the instance row
+    const InstanceRec& inst = sc.instances[pv.inst];
     const RMat* mat = sc.rmats + inst.gpu.material_id;
     const MatHeader mh = material_header(sc, (uint32_t)inst.gpu.material_id);   // issued before the vertex gathers so both are in flight together
-    HitGeom va = get_vertex_attributes(inst, sc.shade + hit.tri, v3(1 - hit.u - hit.v, hit.u, hit.v));
+    HitGeom va = get_vertex_attributes(inst, pv, v3(1 - hit.u - hit.v, hit.u, hit.v));
     const int dbg = fc.debug_output;
     if (dbg >= PT_DEBUG_OUTPUT_HIT_KIND && dbg <= PT_DEBUG_OUTPUT_TEXCOORD_1) {                       // :806-840
         vec3 c;
