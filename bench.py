@@ -29,7 +29,7 @@ ranks in the K steps / that time.  Rays are counted by the kernel itself (every 
 
 Extra objects on the JSON line:
   roofline     - the wavefront pipeline of one pt_trace (one launch = one step = S samples): algorithmic bytes per
-                 launch (counted by an untimed instrumented replay of the same K frames: nodes*128 +
+                 launch (counted by an untimed instrumented replay of the same K frames: nodes*64 +
                  tris*48 + hits*S_hit + taps*16 + env loads + 32 B/pixel) / mean per-frame kernel time
                  measured live with HIP events on the launch stream; peak = 8 TB/s HBM; traffic =
                  PMC-measured HBM bytes per launch from profiles/pmc_traffic.json (same command), or null.
@@ -281,9 +281,9 @@ def main():
         n = float(args.steps)
         env_mis = bool(settings.flags & abi.FLAG_ENVIRONMENT_MIS) and bool(settings.flags & abi.FLAG_ENVIRONMENT_MAP)
         # bytes/ray = N_node*node_size + N_tri*48 + [closest hits] S_hit + 32/R per pixel-sample.  Node size is
-        # 128 B (the 4-wide node this build uses; the survey's 64 B assumed binary nodes).
+        # 64 B (the quantised 4-wide node of this build; the survey's figure).
         s_hit = 12 + 3 * (12 + 4 + 8) + 176 + 640            # indices + 3 vertices + instance row + material
-        alg = (c.nodes_visited * 128 + c.tris_tested * 48 + c.closest_hits * s_hit + c.texture_taps * 16
+        alg = (c.nodes_visited * 64 + c.tris_tested * 48 + c.closest_hits * s_hit + c.texture_taps * 16
                + (c.closest_hits * 40 * 4 if env_mis else 0) + (c.rays_primary + c.rays_bounce - c.closest_hits) * 64) / n + s.width * s.height * 32 * spp
         mean_ms = sum(kernel_ms) / len(kernel_ms)
         achieved = alg / (mean_ms * 1e-3) / 1e9
