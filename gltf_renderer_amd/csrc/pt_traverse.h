@@ -24,7 +24,10 @@
 
 namespace pt {
 
-constexpr int kStackLds = 24;       // entries per lane in LDS  (24 * 4 B * 256 lanes = 24 KiB per workgroup)
+#ifndef PT_STACK_LDS
+#define PT_STACK_LDS 24
+#endif
+constexpr int kStackLds = PT_STACK_LDS;       // entries per lane in LDS  (24 * 4 B * 256 lanes = 24 KiB per workgroup)
 constexpr int kStackSpill = 40;     // further entries in scratch
 constexpr int kBlock = 256;
 constexpr int kTravDone = (int)0x80000000;   // `cur` value of a finished ray (leaf refs are ~tri > INT_MIN)
