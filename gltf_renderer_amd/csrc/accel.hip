@@ -282,28 +282,25 @@ __device__ __forceinline__ void seg_query(const SegBox* __restrict__ T, uint32_t
     lo[0] = b[0]; lo[1] = b[1]; lo[2] = b[2]; hi[0] = b[3]; hi[1] = b[4]; hi[2] = b[5];
 }
 
+// The ranges of a radix-tree node's two children, from the node alone: it covers [first, first + count) and splits after gamma,
+// which is the index of its left child whatever that is (leaf gamma or inner node gamma; the right child is gamma + 1).
+struct ChildRanges { uint32_t f0, k0, f1, k1; };
+__device__ __forceinline__ ChildRanges child_ranges(const BvhNode& n) {
+    const uint32_t first = n._pad[0], count = n._pad[1];
+    const uint32_t gamma = (uint32_t)(n.child0 < 0 ? ~n.child0 : n.child0);
+    ChildRanges r;
+    r.f0 = first; r.k0 = gamma - first + 1u; r.f1 = gamma + 1u; r.k1 = count - r.k0;
+    return r;
+}
+
 // one lane per radix-tree node: the boxes of its two children
 __global__ __launch_bounds__(256) void k_fit(const SegBox* __restrict__ T, uint32_t P, uint32_t n_nodes, BvhNode* __restrict__ nodes) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
     BvhNode& n = nodes[i];
-    const int32_t c0 = n.child0, c1 = n.child1;
-    uint32_t f0, k0, f1, k1;
-    if (c0 < 0) { f0 = (uint32_t)~c0; k0 = 1; } else { f0 = nodes[c0]._pad[0]; k0 = nodes[c0]._pad[1]; }
-    if (c1 < 0) { f1 = (uint32_t)~c1; k1 = 1; } else { f1 = nodes[c1]._pad[0]; k1 = nodes[c1]._pad[1]; }
-    seg_query(T, P, f0, k0, n.lo0, n.hi0);
-    seg_query(T, P, f1, k1, n.lo1, n.hi1);
-}
-
-// 6. collapse to 4-wide (PT_GREEDY_COLLAPSE=0 variant).  Binary nodes at even depth are kept; each gathers its (up to 4)
-//    grandchildren, whose boxes are already stored in the intermediate (odd-depth) nodes.
-__global__ __launch_bounds__(256) void k_mark_kept(const int32_t* __restrict__ node_parent, uint32_t n_nodes, uint32_t* __restrict__ kept) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_nodes) return;
-    uint32_t depth = 0;
-    int code = node_parent[i];
-    while (code >= 0) { depth++; code = node_parent[code >> 1]; }
-    kept[i] = (depth & 1u) ? 0u : 1u;
+    const ChildRanges r = child_ranges(n);
+    seg_query(T, P, r.f0, r.k0, n.lo0, n.hi0);
+    seg_query(T, P, r.f1, r.k1, n.lo1, n.hi1);
 }
 
 // Writes one 64-B wide node: the children's boxes on the 8-bit grid of the node's own box (pt_types.h Bvh4Node).  Conservative:
@@ -337,59 +334,24 @@ __device__ void wide_write(Bvh4Node* dst, const float (*lo)[3], const float (*hi
     for (int q = 0; q < 4; q++) d[q] = make_uint4(word[4 * q], word[4 * q + 1], word[4 * q + 2], word[4 * q + 3]);
 }
 
-__global__ __launch_bounds__(256) void k_collapse(const BvhNode* __restrict__ nodes2, uint32_t n_nodes, const uint32_t* __restrict__ kept,
-                                                  const uint32_t* __restrict__ widx, Bvh4Node* __restrict__ out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_nodes || !kept[i]) return;
-    const BvhNode& n = nodes2[i];
-    float lo[4][3], hi[4][3];
-    int32_t ref[4];
-    int k = 0;
-    auto put = [&](const float* l, const float* h, int32_t r) { for (int a = 0; a < 3; a++) { lo[k][a] = l[a]; hi[k][a] = h[a]; } ref[k] = r; k++; };
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-        const int32_t ch = c ? n.child1 : n.child0;
-        if (ch < 0) put(c ? n.lo1 : n.lo0, c ? n.hi1 : n.hi0, ch);     // leaf child stays a leaf
-        else {                                                         // odd-depth inner node: adopt its two children
-            const BvhNode& m = nodes2[ch];
-            put(m.lo0, m.hi0, m.child0 < 0 ? m.child0 : (int32_t)widx[m.child0]);
-            put(m.lo1, m.hi1, m.child1 < 0 ? m.child1 : (int32_t)widx[m.child1]);
-        }
-    }
-    wide_write(out + widx[i], lo, hi, ref, k);
-}
-
-#ifndef PT_GREEDY_COLLAPSE
-#define PT_GREEDY_COLLAPSE 1
-#endif
-constexpr bool kGreedyCollapse = PT_GREEDY_COLLAPSE != 0;
-
-constexpr int kCollapseMaxLevels = 4096;
-__global__ __launch_bounds__(256) void k_collapse_init(uint32_t* __restrict__ frontier, uint32_t* __restrict__ widx, uint32_t* __restrict__ counters) {
-    for (int k = threadIdx.x; k < kCollapseMaxLevels + 16; k += 256) counters[k] = k <= 1 ? 1u : 0u;   // one wide node (the root), level 0 holds one entry
-    if (threadIdx.x == 0) { frontier[0] = 0u; widx[0] = 0u; }                                       // binary node 0 -> wide node 0
-}
-
-// 6'. collapse to 4-wide, greedily by surface area (one launch per level of the WIDE tree, top down).  A frontier entry is a
-//     binary node that becomes a wide node; it starts with its two children and keeps opening the inner child with the largest
-//     box until it holds four children or only leaves.  Compared with "keep every even level" this fills the slots (about 3.0 ->
-//     3.6 children per node on the Sponza-class scene), so the tree is shallower and a ray visits fewer nodes.
-__global__ __launch_bounds__(256) void k_collapse_level(const BvhNode* __restrict__ nodes2, const uint32_t* __restrict__ frontier_in,
-                                                        const uint32_t* __restrict__ widx_in, uint32_t level, uint32_t* __restrict__ frontier_out,
-                                                        uint32_t* __restrict__ widx_out, uint32_t* __restrict__ counters, Bvh4Node* __restrict__ out) {
-    // counters[0]: wide nodes allocated so far; counters[1 + L]: size of level L's frontier.  The host launches several levels
-    // without looking (grids sized for the largest frontier the level can have), so a level may well be empty.
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= counters[1 + level]) return;
-    // an inner subtree of at most kLeafMax triangles becomes ONE leaf reference (its triangles are contiguous): the bottom of a
-    // binary tree is full of 2- and 3-triangle subtrees, which as wide nodes would spend a whole node step on two boxes
-    auto child_ref = [&](int32_t r) -> int32_t {
-        if (r < 0) return r;
-        const uint32_t first = nodes2[r]._pad[0], count = nodes2[r]._pad[1];
-        return count <= (uint32_t)kLeafMax ? ~(int32_t)(first | ((count - 1u) << 28)) : r;
+// 6. collapse to 4-wide, greedily by surface area, level by level of the WIDE tree, top down.  A frontier entry is a binary node
+//    that becomes a wide node; it starts with its two children and keeps opening the inner child with the largest box until it
+//    holds four children or only leaves.  Compared with "keep every even level of the binary tree" this fills the slots (about
+//    3.0 -> 3.6 children per node on the Sponza-class scene), so the tree is shallower and a ray visits fewer nodes.
+//    counters[0]: wide nodes allocated so far; counters[1 + L]: size of level L's frontier.
+__device__ void collapse_one(const BvhNode* __restrict__ nodes2, uint32_t binary_node, uint32_t wide_index, uint32_t level,
+                             uint32_t* __restrict__ frontier_out, uint32_t* __restrict__ widx_out, uint32_t* __restrict__ counters,
+                             Bvh4Node* __restrict__ out) {
+    // References while collapsing: a binary node index (>= 0) or a leaf reference (< 0).  An inner subtree of at most kLeafMax
+    // triangles becomes ONE leaf (its triangles are contiguous): the bottom of a binary tree is full of 2- and 3-triangle
+    // subtrees, which as wide nodes would spend a whole node step on two boxes.  Its size follows from the parent's range.
+    auto child_ref = [](int32_t child, uint32_t first, uint32_t count) -> int32_t {
+        if (child < 0) return child;
+        return count <= (uint32_t)kLeafMax ? ~(int32_t)(first | ((count - 1u) << 28)) : child;
     };
-    const BvhNode& n = nodes2[frontier_in[i]];
-    int32_t ref[4] = {child_ref(n.child0), child_ref(n.child1), kEmptyChild, kEmptyChild};
+    const BvhNode& n = nodes2[binary_node];
+    const ChildRanges nr = child_ranges(n);
+    int32_t ref[4] = {child_ref(n.child0, nr.f0, nr.k0), child_ref(n.child1, nr.f1, nr.k1), kEmptyChild, kEmptyChild};
     float lo[4][3], hi[4][3];
     for (int a = 0; a < 3; a++) { lo[0][a] = n.lo0[a]; hi[0][a] = n.hi0[a]; lo[1][a] = n.lo1[a]; hi[1][a] = n.hi1[a]; }
     int cnt = 2;
@@ -404,7 +366,8 @@ __global__ __launch_bounds__(256) void k_collapse_level(const BvhNode* __restric
         }
         if (pick < 0) break;
         const BvhNode& m = nodes2[ref[pick]];
-        ref[pick] = child_ref(m.child0); ref[cnt] = child_ref(m.child1);
+        const ChildRanges mr = child_ranges(m);
+        ref[pick] = child_ref(m.child0, mr.f0, mr.k0); ref[cnt] = child_ref(m.child1, mr.f1, mr.k1);
         for (int a = 0; a < 3; a++) { lo[pick][a] = m.lo0[a]; hi[pick][a] = m.hi0[a]; lo[cnt][a] = m.lo1[a]; hi[cnt][a] = m.hi1[a]; }
         cnt++;
     }
@@ -434,13 +397,46 @@ __global__ __launch_bounds__(256) void k_collapse_level(const BvhNode* __restric
             slot++;
         }
     }
-    wide_write(out + widx_in[i], lo, hi, ref, cnt);
+    wide_write(out + wide_index, lo, hi, ref, cnt);
+}
+
+constexpr int kCollapseMaxLevels = 4096;
+__global__ __launch_bounds__(256) void k_collapse_init(uint32_t* __restrict__ frontier, uint32_t* __restrict__ widx, uint32_t* __restrict__ counters) {
+    for (int k = threadIdx.x; k < kCollapseMaxLevels + 16; k += 256) counters[k] = k <= 1 ? 1u : 0u;   // one wide node (the root), level 0 holds one entry
+    if (threadIdx.x == 0) { frontier[0] = 0u; widx[0] = 0u; }                                       // binary node 0 -> wide node 0
+}
+
+// One level per launch (large scenes).  The host launches several levels without looking, with grids sized for the largest
+// frontier the level can have, so a level may well be empty.
+__global__ __launch_bounds__(256) void k_collapse_level(const BvhNode* __restrict__ nodes2, const uint32_t* __restrict__ frontier_in,
+                                                        const uint32_t* __restrict__ widx_in, uint32_t level, uint32_t* __restrict__ frontier_out,
+                                                        uint32_t* __restrict__ widx_out, uint32_t* __restrict__ counters, Bvh4Node* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= counters[1 + level]) return;
+    collapse_one(nodes2, frontier_in[i], widx_in[i], level, frontier_out, widx_out, counters, out);
+}
+
+// All levels in one launch of ONE workgroup (small scenes: a rebuild per animation frame is launch-bound, and sixteen level
+// launches were 0.22 of its 0.39 ms).  Levels are separated by workgroup barriers; the frontier ping-pongs between fr[0] and fr[1].
+constexpr uint32_t kSmallCollapseNodes = 32768;
+__global__ __launch_bounds__(1024) void k_collapse_small(const BvhNode* __restrict__ nodes2, uint32_t* fr0, uint32_t* wi0, uint32_t* fr1, uint32_t* wi1,
+                                                         uint32_t* counters, Bvh4Node* __restrict__ out) {
+    for (uint32_t level = 0; level < (uint32_t)kCollapseMaxLevels; level++) {
+        // (the counters are advanced by agent-scope atomics, which are performed in L2 and leave this CU's L1 copy of the line stale)
+        const uint32_t n_in = __hip_atomic_load(counters + 1 + level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n_in == 0) break;                                        // the same for every lane: no barrier is skipped by some
+        uint32_t* fin = (level & 1u) ? fr1 : fr0;  uint32_t* win = (level & 1u) ? wi1 : wi0;
+        uint32_t* fout = (level & 1u) ? fr0 : fr1; uint32_t* wout = (level & 1u) ? wi0 : wi1;
+        for (uint32_t i = threadIdx.x; i < n_in; i += blockDim.x) collapse_one(nodes2, fin[i], win[i], level, fout, wout, counters, out);
+        __threadfence_block();
+        __syncthreads();
+    }
 }
 
 static void free_all(AccelScratch& s) {
     hipFree(s.tris_unsorted); hipFree(s.keys_a); hipFree(s.keys_b); hipFree(s.vals_a); hipFree(s.vals_b);
     hipFree(s.leaf_parent); hipFree(s.node_parent); hipFree(s.seg); hipFree(s.block_bounds); hipFree(s.sort_temp);
-    hipFree(s.nodes2); hipFree(s.kept); hipFree(s.widx); hipFree(s.scan_temp); hipFree(s.collapse_counters);
+    hipFree(s.nodes2); hipFree(s.kept); hipFree(s.widx); hipFree(s.collapse_counters);
 }
 
 static hipError_t ensure(AccelScratch& s, size_t n) {
@@ -470,10 +466,6 @@ static hipError_t ensure(AccelScratch& s, size_t n) {
     if ((e = rocprim::radix_sort_pairs(nullptr, tb, s.keys_a, s.keys_b, s.vals_a, s.vals_b, cap, 0, 63, (hipStream_t)0))) return e;
     if ((e = hipMalloc(&s.sort_temp, tb))) return e;
     s.sort_temp_bytes = tb;
-    size_t sb = 0;
-    if ((e = rocprim::exclusive_scan(nullptr, sb, s.kept, s.widx, 0u, cap + 1, rocprim::plus<uint32_t>(), (hipStream_t)0))) return e;
-    if ((e = hipMalloc(&s.scan_temp, sb))) return e;
-    s.scan_temp_bytes = sb;
     if ((e = hipMalloc(&s.collapse_counters, (kCollapseMaxLevels + 16) * 4))) return e;
     s.capacity = cap;
     return hipSuccess;
@@ -519,20 +511,15 @@ hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const Instan
         }
         hipLaunchKernelGGL(k_fit, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, T, P, n_nodes, s.nodes2);
     }
-    if (!kGreedyCollapse) {
-        hipLaunchKernelGGL(k_mark_kept, dim3(g), dim3(256), 0, stream, s.node_parent, n_nodes, s.kept);
-        if ((e = hipMemsetAsync(s.kept + n_nodes, 0, 4, stream))) return e;            // sentinel: widx[n_nodes] = total kept
-        size_t sb = s.scan_temp_bytes;
-        if ((e = rocprim::exclusive_scan(s.scan_temp, sb, s.kept, s.widx, 0u, (size_t)n_nodes + 1, rocprim::plus<uint32_t>(), stream))) return e;
-        hipLaunchKernelGGL(k_collapse, dim3(g), dim3(256), 0, stream, s.nodes2, n_nodes, s.kept, s.widx, d_nodes);
-        if ((e = hipGetLastError())) return e;
-        if ((e = hipMemcpyAsync(wide_nodes_out, s.widx + n_nodes, 4, hipMemcpyDeviceToHost, stream))) return e;
-        return hipStreamSynchronize(stream);
-    }
     // greedy collapse, level by level: frontier = binary nodes that become wide nodes, with the wide index their parent gave them
     uint32_t* fr[2] = {s.kept, s.vals_a};
     uint32_t* wi[2] = {s.widx, s.vals_b};                            // (the sort's value buffers are free again by now)
     hipLaunchKernelGGL(k_collapse_init, dim3(1), dim3(256), 0, stream, fr[0], wi[0], s.collapse_counters);
+    if (n_nodes <= kSmallCollapseNodes) {
+        hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(1024), 0, stream, s.nodes2, fr[0], wi[0], fr[1], wi[1], s.collapse_counters, d_nodes);
+        *wide_nodes_out = kWideNodesOnDevice;                       // no host round trip on this path: read s.collapse_counters[0] when asked
+        return hipGetLastError();
+    }
     // Levels are launched eight at a time with grids sized for the largest frontier each can have (four times the one before,
     // at most every node); the kernels read the true sizes from the device, the host looks once per eight levels.
     uint32_t bound = 1;

@@ -670,6 +670,8 @@ int pt_get_stats(pt_ctx* ctx, pt_stats* out) {
     if (ctx->have_accel) hipEventElapsedTime(&out->accel_ms, ctx->ev_accel[0], ctx->ev_accel[1]);
     if (ctx->have_skin) hipEventElapsedTime(&out->skin_ms, ctx->ev_skin[0], ctx->ev_skin[1]);
     out->accumulated_frames = ctx->accumulated_frames;
+    if (ctx->wide_nodes == kWideNodesOnDevice)      // small scene: the build did not wait for the count (pt_host.h)
+        HIPOK(hipMemcpy(&ctx->wide_nodes, ctx->scratch.collapse_counters, 4, hipMemcpyDeviceToHost));
     out->bvh_nodes = ctx->wide_nodes;
     out->bvh_triangles = ctx->n_tris;
     if (c.stack_overflow) return ctx->fail(PT_ERR_CAPACITY, "traversal stack overflow: " + std::to_string(c.stack_overflow) + " pushes dropped");

@@ -20,16 +20,16 @@ struct AccelScratch {
     void* sort_temp = nullptr;
     size_t sort_temp_bytes = 0;
     BvhNode* nodes2 = nullptr;       // the binary LBVH (intermediate)
-    uint32_t* kept = nullptr;        // 1 for binary nodes at even depth: they become 4-wide nodes
-    uint32_t* widx = nullptr;        // exclusive scan of kept = wide node index
-    void* scan_temp = nullptr;
-    size_t scan_temp_bytes = 0;
+    uint32_t* kept = nullptr;        // collapse frontier (ping): binary nodes that become wide nodes
+    uint32_t* widx = nullptr;        // ... and the wide-node index each was given
     uint32_t* collapse_counters = nullptr;   // greedy collapse: [0] wide nodes allocated, [1 + L] frontier size of level L
     size_t capacity = 0;
 };
 void accel_scratch_free(AccelScratch& s);
 // Builds the 4-wide BVH (<= n_tris nodes), the sorted intersection packets and their shading packets (n_tris each).
-// root_out: 0, or ~0 for a single triangle.
+// root_out: 0, or ~0 for a single triangle.  wide_nodes_out: the node count, or kWideNodesOnDevice when the build did not wait
+// for it (small scenes): it is then s.collapse_counters[0] once the stream has caught up.
+constexpr uint32_t kWideNodesOnDevice = 0xffffffffu;
 hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const InstanceRec* d_instances, int n_inst, uint32_t n_tris, Bvh4Node* d_nodes,
                        TriPacket* d_tris, ShadePacket* d_shade, int32_t* root_out, uint32_t* wide_nodes_out, hipStream_t stream);
 
