@@ -463,6 +463,7 @@ struct Loader {
             const Accessor* ia = accessor(idx_acc);
             if (!ia) return false;
             p.num_indices = (int)ia->count;
+            if (ia->ncomp != 1) { err = "glTF: index accessor must be SCALAR"; return false; }       // (the raw copy below writes ncomp components per element)
             if (ia->component == CT_UBYTE || ia->component == CT_USHORT) p.index_format = PT_FORMAT_R16_UINT;
             else if (ia->component == CT_UINT) p.index_format = PT_FORMAT_R32_UINT;
             else { err = "glTF: index accessor must be u8 / u16 / u32"; return false; }

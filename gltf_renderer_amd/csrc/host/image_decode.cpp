@@ -411,13 +411,14 @@ struct JDec {
     void reset() { bitbuf = 0; bitcnt = 0; marker = -1; nomore = false; eobrun = 0; for (int i = 0; i < 4; i++) comp[i].dc_pred = 0; }
 };
 
-inline uint8_t clamp8(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+inline uint8_t clamp8(long long x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
 
-// stb_image's integer IDCT (the libjpeg "islow" factorisation with 12-bit constants), dequantised input.
-#define JF2F(x) ((int)(((x) * 4096 + 0.5)))
+// stb_image's integer IDCT (the libjpeg "islow" factorisation with 12-bit constants), dequantised input.  The arithmetic is
+// 64-bit so that the coefficients of a damaged file cannot overflow it (a valid stream stays far inside 32 bits: same results).
+#define JF2F(x) ((long long)(((x) * 4096 + 0.5)))
 #define JFSH(x) ((x) * 4096)
 #define JIDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                                                            \
-    int t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                                 \
+    long long t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                           \
     p2 = s2; p3 = s6;                                                                                       \
     p1 = (p2 + p3) * JF2F(0.5411961f);                                                                      \
     t2 = p1 + p3 * JF2F(-1.847759065f);                                                                     \
@@ -434,11 +435,11 @@ inline uint8_t clamp8(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x))
     t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
 
 void idct_block(uint8_t* out, int out_stride, const int16_t* data) {
-    int val[64], *v = val;
+    long long val[64], *v = val;
     const int16_t* d = data;
     for (int i = 0; i < 8; ++i, ++d, ++v) {
         if (d[8] == 0 && d[16] == 0 && d[24] == 0 && d[32] == 0 && d[40] == 0 && d[48] == 0 && d[56] == 0) {
-            int dcterm = d[0] * 4;
+            long long dcterm = d[0] * 4;
             v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dcterm;
         } else {
             JIDCT_1D(d[0], d[8], d[16], d[24], d[32], d[40], d[48], d[56])
@@ -923,8 +924,9 @@ bool decode_exr(const uint8_t* data, size_t n, ImageF& out, std::string& err, bo
     if (!have_dw || chans.empty() || compression < 0) { err = "exr: missing required attributes"; return false; }
     if (compression > 9) { err = "exr: unknown compression type"; return false; }
     for (auto& c : chans) if (c.xs != 1 || c.ys != 1) { err = "exr: sub-sampled channels are unsupported"; return false; }
-    const int w = dw[2] - dw[0] + 1, h = dw[3] - dw[1] + 1;
-    if (w <= 0 || h <= 0 || w > (1 << 16) || h > (1 << 16)) { err = "exr: bad data window"; return false; }
+    const long long w64 = (long long)dw[2] - dw[0] + 1, h64 = (long long)dw[3] - dw[1] + 1;
+    if (w64 <= 0 || h64 <= 0 || w64 > (1 << 16) || h64 > (1 << 16)) { err = "exr: bad data window"; return false; }
+    const int w = (int)w64, h = (int)h64;
     if (chans[0].type != 1 && chans[0].type != 2) { err = "exr: unsupported pixel type"; return false; }              // EnvironmentMap.cpp:177-185
     int ci[3] = {-1, -1, -1};
     for (size_t i = 0; i < chans.size(); i++) { if (chans[i].name == "R") ci[0] = (int)i; else if (chans[i].name == "G") ci[1] = (int)i; else if (chans[i].name == "B") ci[2] = (int)i; }
@@ -946,10 +948,11 @@ bool decode_exr(const uint8_t* data, size_t n, ImageF& out, std::string& err, bo
     std::vector<uint8_t> buf, tmp;
     for (int b = 0; b < nblocks; b++) {
         uint64_t off = le64(pos + (size_t)b * 8);
-        if (off + 8 > n) { err = "exr: bad block offset"; return false; }
-        int y0 = (int)le32((size_t)off) - dw[1];
+        if (off > n || n - off < 8) { err = "exr: bad block offset"; return false; }                 // (off + 8 could wrap)
+        const long long y64 = (long long)(int)le32((size_t)off) - dw[1];
         uint32_t sz = le32((size_t)off + 4);
-        if (off + 8 + sz > n || y0 < 0 || y0 >= h) { err = "exr: bad block"; return false; }
+        if (off + 8 + sz > n || y64 < 0 || y64 >= h) { err = "exr: bad block"; return false; }
+        const int y0 = (int)y64;
         const int lines = (y0 + lines_per_block <= h) ? lines_per_block : h - y0;
         const size_t expect = (size_t)lines * w * bytes_per_px_row;
         const uint8_t* src = data + off + 8;

@@ -427,6 +427,12 @@ def test_loader_errors_are_reported_not_crashes(tmp_path):
     b.node(root=True, mesh=b.mesh([{"attributes": {"POSITION": pos}, "indices": idx}]))
     with pytest.raises(MiptError, match="index out of"):
         G.GltfScene(b.write_glb(str(tmp_path / "badindex.glb")))
+    b = Builder()                                                       # found by tests/fuzz: a VEC4 accessor used as the index stream
+    pos = b.accessor(np.zeros((3, 3), np.float32))
+    idx = b.accessor(np.zeros((3, 4), np.uint16))
+    b.node(root=True, mesh=b.mesh([{"attributes": {"POSITION": pos}, "indices": idx}]))
+    with pytest.raises(MiptError, match="SCALAR"):
+        G.GltfScene(b.write_glb(str(tmp_path / "vec4index.glb")))
     b = Builder()
     b.j["accessors"].append({"bufferView": 5, "componentType": 5126, "count": 3, "type": "VEC3"})
     b.node(root=True, mesh=b.mesh([{"attributes": {"POSITION": 0}}]))
@@ -586,6 +592,14 @@ def test_exr_rejects_what_the_reference_rejects():
         G.decode_rgb32f(exr_file(big, np.float32, 3).replace(b"compression\0compression\0\x01\0\0\0\x03", b"compression\0compression\0\x01\0\0\0\x05"), True)
     with pytest.raises(MiptError):
         G.decode_rgb32f(good[:100], True)
+    # found by tests/fuzz: a block offset of 2^64 - 1 (offset + 8 wrapped) and a data window whose extent overflows an int
+    hdr_end = len(good) - (4 * (8 + 8 + 4 * 4 * 3))                      # 4 one-line blocks: offset table + (y, size, 3 float rows of 4)
+    with pytest.raises(MiptError):
+        G.decode_rgb32f(good[:hdr_end] + b"\xff" * 8 + good[hdr_end + 8:], True)
+    wide = good.replace(struct.pack("<4i", 0, 0, 3, 3), struct.pack("<4i", -2147483648, 0, 18, 3))
+    assert wide != good
+    with pytest.raises(MiptError, match="data window"):
+        G.decode_rgb32f(wide, True)
 
 
 def test_sheen_lut_exr_of_the_reference_matches_the_committed_table():
