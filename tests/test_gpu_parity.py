@@ -390,6 +390,35 @@ def test_argument_validation_returns_errors_not_faults(R):
     r.close()
 
 
+def test_edge_cases_empty_tiny_and_ragged(R, oracle_lib):
+    """Empty and ragged inputs: a scene without geometry, the smallest trees (1, 2, 3 and 5 triangles: leaf root, one node, one node
+    with a 3-triangle leaf, two levels), frames that are not multiples of the 16x16 tile or are smaller than one wave."""
+    f32 = np.float32
+    def tri_scene(n_tris, w, h):
+        s = scenes.single_triangle(16)
+        s.instances.clear(); s.mesh_records.clear(); s.buffers.clear(); s.triangles = 0
+        for k in range(n_tris):
+            z = 0.4 * k
+            m = meshgen.Mesh(np.array([[-1 + 0.1 * k, 0.2 * k, -1 + z], [1, 0.2 * k, -1 + z], [0, 0.2 * k, 0.2 + z]], f32), np.array([0, 1, 2]),
+                             normals=np.array([[0, -1, 0]] * 3, f32), uv0=np.array([[0, 1], [1, 1], [0.5, 0]], f32))
+            s.add_mesh(m, None, 0)
+        s.width, s.height = w, h
+        return s
+    cases = [(0, 40, 24), (1, 1, 1), (2, 17, 3), (3, 33, 65), (5, 16, 16), (5, 7, 130)]
+    for n_tris, w, h in cases:
+        p = Pair(R, oracle_lib, tri_scene(n_tris, w, h))
+        for dbg in (abi.DEBUG_OUTPUT_NONE, abi.DEBUG_OUTPUT_HIT_KIND, abi.DEBUG_OUTPUT_TEXCOORD_0):
+            st = copy_settings(p.s.settings); st.debug_output = dbg
+            og, b = p.render(settings=st)
+            a = p.r.readback(og)
+            assert a.shape == b.shape == (h, w, 4)
+            assert np.abs(a - b).max() < 1e-5, (n_tris, w, h, dbg)
+        sg, so = p.r.stats(), p.o.counters()
+        assert (sg.rays_primary, sg.rays_bounce, sg.rays_shadow) == (so["primary"], so["bounce"], so["shadow"]), (n_tris, w, h)
+        assert sg.bvh_triangles == n_tris
+        p.close()
+
+
 # ---- BASELINE-size property tests (no oracle at this size: size-independent identities) --------------------------
 @pytest.fixture(scope="module")
 def sponza(R):
