@@ -51,6 +51,7 @@ struct pt_ctx {
     std::vector<EnvDevice*> envs;
     float* d_sheen = nullptr;
     float* d_srgb = nullptr;
+    float2* d_tangent_lut = nullptr;
     Counters* d_counters = nullptr;
     void* d_bones = nullptr; size_t bones_cap = 0;
     void* d_workspace = nullptr; size_t workspace_cap = 0;     // wavefront ray / hit / path-state arrays
@@ -196,7 +197,7 @@ public:
             sc.rmats = ctx->d_rmats; sc.lights = ctx->d_lights; sc.instances = ctx->d_instances;
             sc.n_materials = (uint32_t)ctx->n_materials; sc.n_instances = (uint32_t)ctx->instances.size();
             sc.nodes = ctx->d_nodes; sc.tris = ctx->d_tris; sc.shade = ctx->d_shade; sc.root = ctx->root; sc.num_tris = ctx->n_tris;
-            sc.sheen_e = ctx->d_sheen; sc.srgb_lut = ctx->d_srgb;
+            sc.sheen_e = ctx->d_sheen; sc.srgb_lut = ctx->d_srgb; sc.tangent_lut = ctx->d_tangent_lut;
             sc.has_env = 0;
             if (ep->environment_map >= 0) {
                 const EnvDevice& ed = *ctx->envs[ep->environment_map];
@@ -377,7 +378,9 @@ int pt_create(int device, void* hip_stream, const float* sheen_e_16x16, pt_ctx**
               hipMemset(ctx->d_white, 0xff, 16) == hipSuccess &&
               hipMemcpy(ctx->d_sheen, sheen_e_16x16, 256 * 4, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpy(ctx->d_srgb, srgb, 256 * 4, hipMemcpyHostToDevice) == hipSuccess &&
-              hipMemset(ctx->d_counters, 0, sizeof(Counters)) == hipSuccess;
+              hipMemset(ctx->d_counters, 0, sizeof(Counters)) == hipSuccess &&
+              hipMalloc((void**)&ctx->d_tangent_lut, 1024 * sizeof(float2)) == hipSuccess &&
+              build_tangent_lut(ctx->d_tangent_lut, ctx->stream) == hipSuccess;
     for (int i = 0; i < 2 && ok; i++)
         ok = hipEventCreate(&ctx->ev_trace[i]) == hipSuccess && hipEventCreate(&ctx->ev_accel[i]) == hipSuccess && hipEventCreate(&ctx->ev_skin[i]) == hipSuccess;
     if (!ok) { pt_destroy(ctx); return PT_ERR_DEVICE; }
@@ -394,7 +397,7 @@ void pt_destroy(pt_ctx* ctx) {
     for (auto& t : ctx->textures) hipFree((void*)t.texels);
     for (auto* e : ctx->envs) { env_free(*e); delete e; }
     hipFree(ctx->d_buffers); hipFree(ctx->d_white); hipFree(ctx->d_rmats); hipFree(ctx->d_lights);
-    hipFree(ctx->d_instances); hipFree(ctx->d_nodes); hipFree(ctx->d_tris); hipFree(ctx->d_shade); hipFree(ctx->d_sheen); hipFree(ctx->d_srgb); hipFree(ctx->d_counters);
+    hipFree(ctx->d_instances); hipFree(ctx->d_nodes); hipFree(ctx->d_tris); hipFree(ctx->d_shade); hipFree(ctx->d_sheen); hipFree(ctx->d_srgb); hipFree(ctx->d_tangent_lut); hipFree(ctx->d_counters);
     accel_scratch_free(ctx->scratch);
     hipFree(ctx->d_bones);
     hipFree(ctx->d_workspace);

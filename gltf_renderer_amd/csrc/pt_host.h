@@ -33,6 +33,9 @@ constexpr uint32_t kWideNodesOnDevice = 0xffffffffu;
 hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const InstanceRec* d_instances, int n_inst, uint32_t n_tris, Bvh4Node* d_nodes,
                        TriPacket* d_tris, ShadePacket* d_shade, int32_t* root_out, uint32_t* wide_nodes_out, hipStream_t stream);
 
+// ---- pt_kernel.hip: 1024 x (sin, cos) of the packed tangent angle
+hipError_t build_tangent_lut(float2* d_lut, hipStream_t stream);
+
 // ---- envmap.hip -------------------------------------------------------------------------------
 struct EnvDevice {
     uint16_t* cube = nullptr;          // all mips, RGBA16F

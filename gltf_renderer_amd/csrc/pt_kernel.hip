@@ -113,4 +113,14 @@ void launch_megakernel(const SceneRec& sc, const FrameConstants& fc, float4* out
     else hipLaunchKernelGGL(pt_megakernel<false>, grid, block, 0, stream, sc, fc, output, counters);
 }
 
+// (sin, cos) table of the packed tangent angle, filled by the decoder's own expression (pt_shading.h)
+__global__ __launch_bounds__(256) void k_tangent_lut(float2* __restrict__ out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < 1024u) out[k] = tangent_sincos_compute(k);
+}
+hipError_t build_tangent_lut(float2* d_lut, hipStream_t stream) {
+    hipLaunchKernelGGL(k_tangent_lut, dim3(4), dim3(256), 0, stream, d_lut);
+    return hipGetLastError();
+}
+
 }  // namespace pt

@@ -55,21 +55,28 @@ PT_DEV void basis_simple(vec3 n, vec3& t, vec3& b) {               // Common.hls
     t = cross(b, n);
 }
 // R10G10B10A2_UNORM fetch + DecodeTangentSpace (Vertex.hlsli:5-19, 46-50).  Tangent comes out negated (quirk q25).
-PT_DEV void decode_tangent_space(uint32_t p, vec3& normal, vec3& tangent, float& winding) {
-    float ex = (float)(p & 0x3ff) / 1023.f, ey = (float)((p >> 10) & 0x3ff) / 1023.f, ez = (float)((p >> 20) & 0x3ff) / 1023.f;
-    float ew = (float)(p >> 30) / 3.f;
+// The tangent's angle has only 1024 values: (sin, cos) of kTau * k / 1023.  The path-tracing kernels read them from a table that
+// k_tangent_lut (pt_kernel.hip) fills with this very function at context creation -- same bits, two full-precision
+// transcendentals per vertex fewer in the shade stage.
+PT_DEV float2 tangent_sincos_compute(uint32_t k) {
+    const float angle = kTau * unorm_div<1023>((float)k);
+    return make_float2(sinf(angle), cosf(angle));
+}
+PT_DEV void decode_tangent_space(uint32_t p, float2 sincos, vec3& normal, vec3& tangent, float& winding) {
+    float ex = unorm_div<1023>((float)(p & 0x3ff)), ey = unorm_div<1023>((float)((p >> 10) & 0x3ff));
     normal = decode_octahedral(ex * 2 - 1, ey * 2 - 1);
     vec3 ct, cb;
     basis_accurate(normal, ct, cb);
-    float angle = kTau * ez;
-    float sn = sinf(angle), cs = cosf(angle);
-    tangent = cs * ct + sn * cb;
-    winding = ew > 0 ? 1.f : -1.f;
+    tangent = sincos.y * ct + sincos.x * cb;
+    winding = (p >> 30) != 0 ? 1.f : -1.f;               // encoded.w > 0, encoded.w = (p >> 30) / 3
+}
+PT_DEV void decode_tangent_space(uint32_t p, vec3& normal, vec3& tangent, float& winding) {
+    decode_tangent_space(p, tangent_sincos_compute((p >> 20) & 0x3ffu), normal, tangent, winding);
 }
 PT_DEV uint32_t encode_tangent_space(vec3 normal, vec3 tangent, float winding) {    // Vertex.hlsli:21-44
     vec2 e = encode_octahedral(normal);
     uint32_t qx = f2u(clampf(0.5f * e.x + 0.5f, 0, 1) * 1023 + 0.5f), qy = f2u(clampf(0.5f * e.y + 0.5f, 0, 1) * 1023 + 0.5f);
-    vec3 nq = decode_octahedral(2.0f * ((float)qx / 1023.0f) - 1.0f, 2.0f * ((float)qy / 1023.0f) - 1.0f);
+    vec3 nq = decode_octahedral(2.0f * unorm_div<1023>((float)qx) - 1.0f, 2.0f * unorm_div<1023>((float)qy) - 1.0f);
     vec3 ct, cb;
     basis_accurate(nq, ct, cb);
     float angle = atan2f(dot(tangent, cb), dot(tangent, ct));
@@ -100,15 +107,23 @@ PT_DEV void stage_luts(const SceneRec& sc) {           // 256-thread workgroups
 }
 PT_DEV float srgb_decode(const float*, uint32_t i) { return pt_lds_lut[i]; }
 PT_DEV float sheen_entry(const float*, int i) { return pt_lds_lut[256 + i]; }
+static __shared__ float2 pt_lds_tangent[1024];         // (sin, cos) of the packed tangent angle; staged by the shade stage only
+PT_DEV void stage_tangent_lut(const SceneRec& sc) {    // 256-thread workgroups
+    for (uint32_t i = threadIdx.x; i < 1024u; i += 256u) pt_lds_tangent[i] = sc.tangent_lut[i];
+    __syncthreads();
+}
+PT_DEV float2 tangent_sincos(const SceneRec&, uint32_t k) { return pt_lds_tangent[k]; }
 #else
 PT_DEV void stage_luts(const SceneRec&) {}
 PT_DEV float srgb_decode(const float* lut, uint32_t i) { return lut[i]; }
 PT_DEV float sheen_entry(const float* lut, int i) { return lut[i]; }
+PT_DEV void stage_tangent_lut(const SceneRec&) {}
+PT_DEV float2 tangent_sincos(const SceneRec& sc, uint32_t k) { return gload_f2(sc.tangent_lut + k); }
 #endif
 PT_DEV vec4 unpack_texel(uint32_t t, uint32_t srgb, const float* lut) {
     uint32_t r = t & 0xff, g = (t >> 8) & 0xff, b = (t >> 16) & 0xff, a = t >> 24;
-    if (srgb) return {srgb_decode(lut, r), srgb_decode(lut, g), srgb_decode(lut, b), (float)a / 255.0f};
-    return {(float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f, (float)a / 255.0f};
+    if (srgb) return {srgb_decode(lut, r), srgb_decode(lut, g), srgb_decode(lut, b), unorm_div<255>((float)a)};
+    return {unorm_div<255>((float)r), unorm_div<255>((float)g), unorm_div<255>((float)b), unorm_div<255>((float)a)};
 }
 PT_DEV float finite_coord(float x) {
     if (!(x == x) || isinf(x)) return 0.f;
@@ -188,7 +203,7 @@ PT_DEV PacketVerts load_shade_packet(const ShadePacket* pk) {
 PT_DEV vec4 fetch_vertex_color(const InstanceRec& in, const PacketVerts& pv, vec3 w) {                // :229-242
     if (!in.p_color) return {1, 1, 1, 1};
     const uint2 q0 = pv.col[0], q1 = pv.col[1], q2 = pv.col[2];
-    auto un = [](uint2 q) { return vec4{(float)(q.x & 0xffff) / 65535.f, (float)(q.x >> 16) / 65535.f, (float)(q.y & 0xffff) / 65535.f, (float)(q.y >> 16) / 65535.f}; };
+    auto un = [](uint2 q) { return vec4{unorm_div<65535>((float)(q.x & 0xffff)), unorm_div<65535>((float)(q.x >> 16)), unorm_div<65535>((float)(q.y & 0xffff)), unorm_div<65535>((float)(q.y >> 16))}; };
     return un(q0) * w.x + un(q1) * w.y + un(q2) * w.z;
 }
 PT_DEV vec2 fetch_texcoord(bool present, const float2 t[3], vec3 w) {                                // :244-257
@@ -202,7 +217,7 @@ struct HitGeom {                       // VertexAttributes, PathTracer.lib.hlsl:
     vec4 color;
     vec2 tc[2];
 };
-PT_DEV HitGeom get_vertex_attributes(const InstanceRec& in, const PacketVerts& pv, vec3 w) {        // :280-302
+PT_DEV HitGeom get_vertex_attributes(const SceneRec& sc, const InstanceRec& in, const PacketVerts& pv, vec3 w) {   // :280-302
     HitGeom a;
     const vec3 p0 = pv.p[0], p1 = pv.p[1], p2 = pv.p[2];
     const bool has_ts = in.p_tangent_space != nullptr;
@@ -217,9 +232,9 @@ PT_DEV HitGeom get_vertex_attributes(const InstanceRec& in, const PacketVerts& p
     if (has_ts) {                                          // :201-222
         vec3 n0, n1, n2, t0, t1, t2;
         float w0, w1, w2;
-        decode_tangent_space(ts0, n0, t0, w0);
-        decode_tangent_space(ts1, n1, t1, w1);
-        decode_tangent_space(ts2, n2, t2, w2);
+        decode_tangent_space(ts0, tangent_sincos(sc, (ts0 >> 20) & 0x3ffu), n0, t0, w0);
+        decode_tangent_space(ts1, tangent_sincos(sc, (ts1 >> 20) & 0x3ffu), n1, t1, w1);
+        decode_tangent_space(ts2, tangent_sincos(sc, (ts2 >> 20) & 0x3ffu), n2, t2, w2);
         n = w.x * n0 + w.y * n1 + w.z * n2;
         t = w.x * t0 + w.y * t1 + w.z * t2;
         tw = w0;                                           // winding from vertex 0 only (quirk q16)

@@ -155,6 +155,7 @@ struct SceneRec {
     uint32_t num_tris;
     const float* sheen_e;       // 16x16
     const float* srgb_lut;      // 256
+    const float2* tangent_lut;  // 1024 x (sin, cos) of the packed tangent angle (pt_shading.h tangent_sincos_compute)
     EnvRec env;
     int32_t has_env;
 };

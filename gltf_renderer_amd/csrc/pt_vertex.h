@@ -51,7 +51,7 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
     const InstanceRec& inst = sc.instances[pv.inst];
     const RMat* mat = sc.rmats + inst.gpu.material_id;
     const MatHeader mh = material_header(sc, (uint32_t)inst.gpu.material_id);   // issued before the vertex gathers so both are in flight together
-    HitGeom va = get_vertex_attributes(inst, pv, v3(1 - hit.u - hit.v, hit.u, hit.v));
+    HitGeom va = get_vertex_attributes(sc, inst, pv, v3(1 - hit.u - hit.v, hit.u, hit.v));
     const int dbg = fc.debug_output;
     if (dbg >= PT_DEBUG_OUTPUT_HIT_KIND && dbg <= PT_DEBUG_OUTPUT_TEXCOORD_1) {                       // :806-840
         vec3 c;

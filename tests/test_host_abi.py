@@ -155,3 +155,30 @@ def test_sponza_class_scene_shape():
     assert len(s.lights) == 6 and sum(1 for l in s.lights if l.type == abi.LIGHT_POINT) == 4
     assert sum(1 for d in s.instances if d.instance_flags & abi.INSTANCE_FLAG_FORCE_NON_OPAQUE) == 10
     assert (s.width, s.height) == (1920, 1080) and s.settings.max_bounces == 8 and s.bounce_limit == 8
+
+
+def test_unorm_division_shortcut_is_exact(tmp_path):
+    """pt_math.h unorm_div<C>: q = x * RN(1/C); q += fma(-C, q, x) * RN(1/C) must equal the IEEE quotient x / C bit for bit for
+    every integer x the decoders feed it (8-, 10- and 16-bit unorm).  Checked on the host with the same three operations."""
+    import shutil, subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "divc.c"
+    src.write_text(r'''
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+static int check(int C, int maxx) {
+    const float c = (float)C, inv = 1.0f / c;
+    int bad = 0;
+    for (int x = 0; x <= maxx; x++) {
+        float fx = (float)x, q = fx * inv, r = fmaf(fmaf(-c, q, fx), inv, q), ref = fx / c;
+        if (memcmp(&r, &ref, 4)) bad++;
+    }
+    return bad;
+}
+int main(void) { int b = check(255, 65535) + check(1023, 65535) + check(65535, 65535); printf("%d\n", b); return b != 0; }
+''')
+    exe = tmp_path / "divc"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), str(src), "-lm"])
+    assert subprocess.run([str(exe)], capture_output=True, text=True).stdout.strip() == "0"
