@@ -42,16 +42,29 @@ PT_DEV vec3 shade_miss(const SceneRec& sc, const FrameConstants& fc, vec3 dir, c
 }
 
 // Returns true when the path ends at this vertex for a debug output (fu.add holds beta * debug colour).
+// -DPT_TIMING (pt_wavefront.hip only; tools/shade_sections.py): cycles per section of this function, summed per wave.
+#ifdef PT_TIMING
+extern __device__ unsigned long long pt_timing[8];
+#define PT_TICK(K) { const unsigned long long _now = __builtin_readcyclecounter(); _sec[K] += _now - _t; _t = _now; }
+#define PT_TICK_FLUSH() { if (__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) { for (int _k = 0; _k < 7; _k++) atomicAdd(&pt_timing[_k], _sec[_k]); atomicAdd(&pt_timing[7], 1ull); } }
+#else
+#define PT_TICK(K)
+#define PT_TICK_FLUSH()
+#endif
 PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint32_t seed, uint32_t px, uint32_t py, const Ray& ray, const HitRec& hit,
                               PathState& ps, Followups& fu, unsigned& taps) {
     const uint32_t flags = fc.flags;
     fu.add = v3(0); fu.overwrite = false; fu.counted_shadow = 0;
     fu.q_env = fu.q_light = fu.q_bounce = false;
+#ifdef PT_TIMING
+    unsigned long long _sec[7] = {0, 0, 0, 0, 0, 0, 0}, _t = __builtin_readcyclecounter();
+#endif
     const PacketVerts pv = load_shade_packet(sc.shade + hit.tri);     // one 128-B line: the three vertices and the instance row
     const InstanceRec& inst = sc.instances[pv.inst];
     const RMat* mat = sc.rmats + inst.gpu.material_id;
     const MatHeader mh = material_header(sc, (uint32_t)inst.gpu.material_id);   // issued before the vertex gathers so both are in flight together
     HitGeom va = get_vertex_attributes(sc, inst, pv, v3(1 - hit.u - hit.v, hit.u, hit.v));
+    PT_TICK(0)
     const int dbg = fc.debug_output;
     if (dbg >= PT_DEBUG_OUTPUT_HIT_KIND && dbg <= PT_DEBUG_OUTPUT_TEXCOORD_1) {                       // :806-840
         vec3 c;
@@ -73,6 +86,7 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
     const vec3 o_above = offset_ray(va.position, va.ng), o_below = offset_ray(va.position, -va.ng);
     const vec3 view = -normalize(ray.d);
     Surface sp = get_surface(sc, flags, mat, mh, va, view, taps);
+    PT_TICK(1)
     if (dbg >= PT_DEBUG_OUTPUT_COLOR && dbg <= PT_DEBUG_OUTPUT_TRANSMISSIVE) {                       // :863-917
         vec3 c;
         switch (dbg) {
@@ -100,6 +114,7 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
     const Lobes lobes = lobe_probabilities(sp, view);
     vec3 c = emissive_of(sc, mat, mh, va.tc, taps);                                                     // :925-926
     fu.origin_above = o_above;
+    PT_TICK(2)
     // environment NEE :929-942 (SampleEnvironmentMap :688-703)
     if (ps.bounce < fc.max_bounces && (flags & PT_FLAG_ENVIRONMENT_MAP) && (flags & PT_FLAG_ENVIRONMENT_MIS)) {
         vec4 r = next_random(px, py, seed, ps.rc);
@@ -127,6 +142,7 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
             if (!(fc.cull_null_shadow && fu.pend_env.x == 0.0f && fu.pend_env.y == 0.0f && fu.pend_env.z == 0.0f)) { fu.q_env = true; fu.env_dir = ldir; }
         }
     }
+    PT_TICK(3)
     // punctual-light NEE :945-956 (SamplePointLight :680-686)
     if ((flags & PT_FLAG_POINT_LIGHTS) && fc.num_of_lights > 0) {
         float u = next_random(px, py, seed, ps.rc).x;
@@ -147,6 +163,7 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
         }
         else c += contrib;
     }
+    PT_TICK(4)
     fu.add = ps.beta * c;
     // BSDF sampling + Russian roulette :958-1006
     if (ps.bounce < fc.max_bounces) {
@@ -191,6 +208,8 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
             }
         }
     }
+    PT_TICK(5)
+    PT_TICK_FLUSH()
     return false;
 }
 

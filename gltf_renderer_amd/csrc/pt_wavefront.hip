@@ -21,6 +21,15 @@
 #include "pt_vertex.h"
 #include "pt_host.h"
 
+#ifdef PT_TIMING                 // diagnostic build only (tools/shade_sections.py); not part of the C-ABI
+namespace pt { __device__ unsigned long long pt_timing[8]; }
+extern "C" int pt_debug_read_timing(unsigned long long* out8, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out8, HIP_SYMBOL(pt::pt_timing), 64);
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(pt::pt_timing), z, 64); }
+    return 0;
+}
+#endif
 namespace pt {
 
 constexpr uint32_t kShards = 256;
