@@ -771,6 +771,22 @@ PT_DEV void importance_step(float ul, float ur, float ll, float lr, float& ux, f
     sx = go_left ? 0u : 1u;
     sy = up ? 0u : 1u;
 }
+// The three coarsest level pairs of the blocked pyramid (4^2, 16^2, 64^2: the first 4368 floats, 17 KB) are staged into LDS by the
+// shade stage: three of the five dependent fetches of the descent become ds_reads of the same values.
+#ifdef PT_LUT_LDS
+constexpr int kImpLdsLevels = 3;
+constexpr uint32_t kImpLdsFloat4 = (16u + 256u + 4096u) / 4u;
+static __shared__ float4 pt_lds_imp[kImpLdsFloat4];
+PT_DEV void stage_importance_top(const SceneRec& sc) {   // 256-thread workgroups
+    if (sc.has_env) for (uint32_t i = threadIdx.x; i < kImpLdsFloat4; i += 256u) pt_lds_imp[i] = gload_f4((const float4*)sc.env.blocked + i);
+    __syncthreads();
+}
+PT_DEV const float4* importance_lds_block(uint32_t float_offset, size_t block) { return pt_lds_imp + float_offset / 4u + block * 4u; }
+#else
+constexpr int kImpLdsLevels = 0;
+PT_DEV void stage_importance_top(const SceneRec&) {}
+PT_DEV const float4* importance_lds_block(uint32_t, size_t) { return nullptr; }
+#endif
 PT_DEV vec2 sample_importance_map(const EnvRec& e, float ux, float uy, float& pdf) {                         // Sampling.hlsli:123-163
     // The reference descends ten levels with four dependent point loads each.  Here one 64-B fetch of a 4x4 block of the
     // finer level of a pair serves two levels: the coarser level's 2x2 values are re-summed from the block in the order the
@@ -780,8 +796,10 @@ PT_DEV vec2 sample_importance_map(const EnvRec& e, float ux, float uy, float& pd
 #pragma unroll 1
     for (int k = 0; k < 5; k++) {
         const uint32_t nb = 1u << (2 * k);                                 // blocks per row of this pair's finer level
-        const float4* blk = (const float4*)(e.blocked + e.blocked_offset[k]) + ((size_t)py * nb + px) * 4;
-        const float4 r0 = blk[0], r1 = blk[1], r2 = blk[2], r3 = blk[3];
+        const size_t block = (size_t)py * nb + px;
+        float4 r0, r1, r2, r3;
+        if (k < kImpLdsLevels) { const float4* blk = importance_lds_block(e.blocked_offset[k], block); r0 = blk[0]; r1 = blk[1]; r2 = blk[2]; r3 = blk[3]; }
+        else { const float4* blk = (const float4*)(e.blocked + e.blocked_offset[k]) + block * 4; r0 = blk[0]; r1 = blk[1]; r2 = blk[2]; r3 = blk[3]; }
         const float a_ul = ((r0.x + r1.x) + r0.y) + r1.y, a_ur = ((r0.z + r1.z) + r0.w) + r1.w;
         const float a_ll = ((r2.x + r3.x) + r2.y) + r3.y, a_lr = ((r2.z + r3.z) + r2.w) + r3.w;
         uint32_t sx, sy, tx, ty;

@@ -223,6 +223,7 @@ PT_DEV void apply_pending(const WfBuffers& wf, uint32_t slot, vec3& L) {
 __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc, FrameConstants fc, WfBuffers wf, int cur, Counters* __restrict__ counters) {
     stage_luts(sc);
     stage_tangent_lut(sc);
+    stage_importance_top(sc);
     stage_materials(sc);
     const ShardView sv = shard_view(wf);
     const uint32_t n = wf.cnt[cur][sv.shard * kCounterStride];
