@@ -694,6 +694,29 @@ PT_DEV vec3 sample_bsdf(uint32_t flags, const float* lut, const Surface& s, cons
 }
 
 // ---------------------------------------------------------------- lights (Lights.hlsli:26-61)
+// The light table is tiny (64 B a light): the shade stage keeps up to kLightCacheMax lights in LDS, so picking one by a per-lane
+// random index is a ds_read instead of a dependent global gather.
+#ifdef PT_LUT_LDS
+constexpr int kLightCacheMax = 32;
+static __shared__ float4 pt_lds_light[kLightCacheMax * 4];
+PT_DEV void stage_lights(const SceneRec& sc, int num_of_lights) {   // 256-thread workgroups
+    const uint32_t n4 = (uint32_t)(num_of_lights < kLightCacheMax ? num_of_lights : kLightCacheMax) * 4u;
+    if (threadIdx.x < n4) pt_lds_light[threadIdx.x] = gload_f4((const float4*)sc.lights + threadIdx.x);
+    __syncthreads();
+}
+PT_DEV pt_light load_light(const SceneRec& sc, uint32_t li) {
+    float4 q[4];
+    if (li < (uint32_t)kLightCacheMax) { const float4* p = pt_lds_light + li * 4u; q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; q[3] = p[3]; }
+    else { const float4* p = (const float4*)sc.lights + (size_t)li * 4u; q[0] = gload_f4(p); q[1] = gload_f4(p + 1); q[2] = gload_f4(p + 2); q[3] = gload_f4(p + 3); }
+    pt_light l;
+    static_assert(sizeof(pt_light) == 64, "pt_light");
+    memcpy(&l, q, 64);
+    return l;
+}
+#else
+PT_DEV void stage_lights(const SceneRec&, int) {}
+PT_DEV pt_light load_light(const SceneRec& sc, uint32_t li) { return sc.lights[li]; }
+#endif
 PT_DEV void light_ray(const pt_light& light, vec3 p, vec3& dir, vec3& color) {
     bool local = light.type == PT_LIGHT_POINT || light.type == PT_LIGHT_SPOT;
     if (local) dir = v3p(light.position) - p;

@@ -150,7 +150,8 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
         li = min(li, (uint32_t)(fc.num_of_lights - 1));                                              // u may be exactly 1 (quirk q17)
         float pdf = 1.0f / (float)fc.num_of_lights;
         vec3 ldir, lcol;
-        light_ray(sc.lights[li], intersection, ldir, lcol);
+        const pt_light light = load_light(sc, li);
+        light_ray(light, intersection, ldir, lcol);
         vec3 contrib = v3(0);
         if (any_gt0(lcol)) {
             float bp = 0;
