@@ -200,8 +200,8 @@ PT_DEV PacketVerts load_shade_packet(const ShadePacket* pk) {
     o.inst = __float_as_uint(f(30));
     return o;
 }
-PT_DEV vec4 fetch_vertex_color(const InstanceRec& in, const PacketVerts& pv, vec3 w) {                // :229-242
-    if (!in.p_color) return {1, 1, 1, 1};
+PT_DEV vec4 fetch_vertex_color(bool present, const PacketVerts& pv, vec3 w) {                         // :229-242
+    if (!present) return {1, 1, 1, 1};
     const uint2 q0 = pv.col[0], q1 = pv.col[1], q2 = pv.col[2];
     auto un = [](uint2 q) { return vec4{unorm_div<65535>((float)(q.x & 0xffff)), unorm_div<65535>((float)(q.x >> 16)), unorm_div<65535>((float)(q.y & 0xffff)), unorm_div<65535>((float)(q.y >> 16))}; };
     return un(q0) * w.x + un(q1) * w.y + un(q2) * w.z;
@@ -217,14 +217,64 @@ struct HitGeom {                       // VertexAttributes, PathTracer.lib.hlsl:
     vec4 color;
     vec2 tc[2];
 };
-PT_DEV HitGeom get_vertex_attributes(const SceneRec& sc, const InstanceRec& in, const PacketVerts& pv, vec3 w) {   // :280-302
+// What a hit needs of its instance row: 96 B instead of the 240-B InstanceRec, so that the rows of up to kInstCacheMax instances
+// fit in LDS in the shade stage and the instance is no longer a second dependent global fetch behind the shading packet.
+struct ShadeInst {
+    float T[16], N[16];                // transform / normal_transform in their column-major slots (only the 12 / 9 used entries are set)
+    uint32_t material_id, streams;     // streams: SI_* presence bits
+};
+enum : uint32_t { SI_TANGENT_SPACE = 1, SI_TEXCOORD0 = 2, SI_TEXCOORD1 = 4, SI_COLOR = 8 };
+PT_DEV ShadeInst shade_inst_unpack(const float4 q[6]) {
+    ShadeInst si;
+    si.T[0] = q[0].x; si.T[1] = q[0].y; si.T[2] = q[0].z; si.T[12] = q[0].w;
+    si.T[4] = q[1].x; si.T[5] = q[1].y; si.T[6] = q[1].z; si.T[13] = q[1].w;
+    si.T[8] = q[2].x; si.T[9] = q[2].y; si.T[10] = q[2].z; si.T[14] = q[2].w;
+    si.N[0] = q[3].x; si.N[1] = q[3].y; si.N[2] = q[3].z; si.material_id = __float_as_uint(q[3].w);
+    si.N[4] = q[4].x; si.N[5] = q[4].y; si.N[6] = q[4].z; si.streams = __float_as_uint(q[4].w);
+    si.N[8] = q[5].x; si.N[9] = q[5].y; si.N[10] = q[5].z;
+    return si;
+}
+PT_DEV void shade_inst_pack(const InstanceRec& in, float4 q[6]) {
+    const float* T = in.gpu.transform; const float* N = in.gpu.normal_transform;
+    const uint32_t streams = (in.p_tangent_space ? SI_TANGENT_SPACE : 0u) | (in.p_texcoord[0] ? SI_TEXCOORD0 : 0u) | (in.p_texcoord[1] ? SI_TEXCOORD1 : 0u) |
+                             (in.p_color ? SI_COLOR : 0u);
+    q[0] = make_float4(T[0], T[1], T[2], T[12]); q[1] = make_float4(T[4], T[5], T[6], T[13]); q[2] = make_float4(T[8], T[9], T[10], T[14]);
+    q[3] = make_float4(N[0], N[1], N[2], __uint_as_float((uint32_t)in.gpu.material_id)); q[4] = make_float4(N[4], N[5], N[6], __uint_as_float(streams));
+    q[5] = make_float4(N[8], N[9], N[10], 0.0f);
+}
+#ifdef PT_LUT_LDS
+constexpr uint32_t kInstCacheMax = 128;
+static __shared__ float4 pt_lds_inst[kInstCacheMax * 6];
+PT_DEV void stage_instances(const SceneRec& sc) {          // 256-thread workgroups
+    const uint32_t n = sc.n_instances < kInstCacheMax ? sc.n_instances : kInstCacheMax;
+    if (threadIdx.x < n) {
+        float4 q[6];
+        shade_inst_pack(sc.instances[threadIdx.x], q);
+#pragma unroll
+        for (int k = 0; k < 6; k++) pt_lds_inst[threadIdx.x * 6u + k] = q[k];
+    }
+    __syncthreads();
+}
+PT_DEV ShadeInst load_shade_inst(const SceneRec& sc, uint32_t id) {
+    float4 q[6];
+    if (id < kInstCacheMax) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) q[k] = pt_lds_inst[id * 6u + k];
+    } else shade_inst_pack(sc.instances[id], q);
+    return shade_inst_unpack(q);
+}
+#else
+PT_DEV void stage_instances(const SceneRec&) {}
+PT_DEV ShadeInst load_shade_inst(const SceneRec& sc, uint32_t id) { float4 q[6]; shade_inst_pack(sc.instances[id], q); return shade_inst_unpack(q); }
+#endif
+PT_DEV HitGeom get_vertex_attributes(const SceneRec& sc, const ShadeInst& in, const PacketVerts& pv, vec3 w) {   // :280-302
     HitGeom a;
     const vec3 p0 = pv.p[0], p1 = pv.p[1], p2 = pv.p[2];
-    const bool has_ts = in.p_tangent_space != nullptr;
+    const bool has_ts = (in.streams & SI_TANGENT_SPACE) != 0;
     const uint32_t ts0 = pv.ts[0], ts1 = pv.ts[1], ts2 = pv.ts[2];
-    a.color = fetch_vertex_color(in, pv, w);
-    a.tc[0] = fetch_texcoord(in.p_texcoord[0] != nullptr, pv.uv0, w);
-    a.tc[1] = fetch_texcoord(in.p_texcoord[1] != nullptr, pv.uv1, w);
+    a.color = fetch_vertex_color((in.streams & SI_COLOR) != 0, pv, w);
+    a.tc[0] = fetch_texcoord((in.streams & SI_TEXCOORD0) != 0, pv.uv0, w);
+    a.tc[1] = fetch_texcoord((in.streams & SI_TEXCOORD1) != 0, pv.uv1, w);
     vec3 pos = w.x * p0 + w.y * p1 + w.z * p2;
     vec3 ng = cross(p1 - p0, p2 - p0);                     // :196-199 un-normalised
     vec3 n, t;
@@ -245,10 +295,10 @@ PT_DEV HitGeom get_vertex_attributes(const SceneRec& sc, const InstanceRec& in, 
         t = normalize(cross(helper, ng));
         tw = 1;
     }
-    a.position = mul_point(in.gpu.transform, pos);
-    a.ng = normalize(mul_dir(in.gpu.normal_transform, ng));
-    a.n = normalize(mul_dir(in.gpu.normal_transform, n));
-    a.t = normalize(mul_dir(in.gpu.transform, t));
+    a.position = mul_point(in.T, pos);
+    a.ng = normalize(mul_dir(in.N, ng));
+    a.n = normalize(mul_dir(in.N, n));
+    a.t = normalize(mul_dir(in.T, t));
     a.tw = tw;
     a.bt = tw * normalize(cross(a.n, a.t));                // :224-227
     return a;

@@ -45,7 +45,7 @@ PT_DEV void candidate_alpha(const SceneRec& sc, uint32_t inst, int tri, float u,
     const InstanceRec& in = sc.instances[inst];
     vec3 w = v3(1 - u - v, u, v);
     const PacketVerts pv = load_shade_packet(sc.shade + tri);
-    vec4 c = fetch_vertex_color(in, pv, w);
+    vec4 c = fetch_vertex_color(in.p_color != nullptr, pv, w);
     vec2 tc[2] = {fetch_texcoord(in.p_texcoord[0] != nullptr, pv.uv0, w), fetch_texcoord(in.p_texcoord[1] != nullptr, pv.uv1, w)};
     base_color_alpha(sc, sc.rmats + in.gpu.material_id, tc, c, taps, base_alpha, alpha, cutoff);
 }

@@ -60,9 +60,9 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
     unsigned long long _sec[7] = {0, 0, 0, 0, 0, 0, 0}, _t = __builtin_readcyclecounter();
 #endif
     const PacketVerts pv = load_shade_packet(sc.shade + hit.tri);     // one 128-B line: the three vertices and the instance row
-    const InstanceRec& inst = sc.instances[pv.inst];
-    const RMat* mat = sc.rmats + inst.gpu.material_id;
-    const MatHeader mh = material_header(sc, (uint32_t)inst.gpu.material_id);   // issued before the vertex gathers so both are in flight together
+    const ShadeInst inst = load_shade_inst(sc, pv.inst);
+    const RMat* mat = sc.rmats + inst.material_id;
+    const MatHeader mh = material_header(sc, inst.material_id);
     HitGeom va = get_vertex_attributes(sc, inst, pv, v3(1 - hit.u - hit.v, hit.u, hit.v));
     PT_TICK(0)
     const int dbg = fc.debug_output;

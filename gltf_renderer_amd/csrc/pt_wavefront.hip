@@ -225,6 +225,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
     stage_tangent_lut(sc);
     stage_importance_top(sc);
     stage_lights(sc, fc.num_of_lights);
+    stage_instances(sc);
     stage_materials(sc);
     const ShardView sv = shard_view(wf);
     const uint32_t n = wf.cnt[cur][sv.shard * kCounterStride];
