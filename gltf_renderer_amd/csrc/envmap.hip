@@ -130,6 +130,8 @@ hipError_t env_build(EnvDevice& e, const float* d_equirect, int w, int h, hipStr
         hipLaunchKernelGGL(k_importance_block, dim3((n + 255) / 256, n), dim3(256), 0, stream, e.importance + e.level_offset[l],
                            e.blocked + e.blocked_offset[k], n);
     }
+    if ((err = hipMemcpyAsync(&e.total, e.importance + e.level_offset[e.levels - 1], 4, hipMemcpyDeviceToHost, stream))) return err;
+    if ((err = hipStreamSynchronize(stream))) return err;
     return hipGetLastError();
 }
 

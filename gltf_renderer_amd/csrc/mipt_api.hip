@@ -203,7 +203,7 @@ public:
                 const EnvDevice& ed = *ctx->envs[ep->environment_map];
                 sc.env.cube = ed.cube; sc.env.cube_n = ed.mip_n[0]; sc.env.importance = ed.importance;
                 for (int i = 0; i < 12; i++) sc.env.level_offset[i] = ed.level_offset[i];
-                sc.env.imp_res = ed.imp_res; sc.env.imp_levels = ed.levels;
+                sc.env.imp_res = ed.imp_res; sc.env.imp_levels = ed.levels; sc.env.imp_total = ed.total;
                 sc.env.blocked = ed.blocked;
                 for (int i = 0; i < 5; i++) sc.env.blocked_offset[i] = ed.blocked_offset[i];
                 sc.has_env = 1;

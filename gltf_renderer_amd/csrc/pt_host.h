@@ -48,6 +48,7 @@ struct EnvDevice {
     int imp_res = 1024;
     float* blocked = nullptr;          // 4x4-blocked copies of levels 4^2, 16^2, 64^2, 256^2, 1024^2 (EnvRec::blocked)
     uint32_t blocked_offset[5] = {0};
+    float total = 0.f;                 // the pyramid's apex (sum of the whole map), read back once: a kernel argument instead of a load per sample
 };
 hipError_t env_build(EnvDevice& e, const float* d_equirect, int w, int h, hipStream_t stream);
 void env_free(EnvDevice& e);

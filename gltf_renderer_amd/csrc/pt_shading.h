@@ -885,11 +885,11 @@ PT_DEV vec2 sample_importance_map(const EnvRec& e, float ux, float uy, float& pd
         py = (py << 2) | (sy << 1) | ty;
     }
     float w = (float)e.imp_res;
-    pdf = w * w * value / imp_load(e, e.imp_levels - 1, 0, 0);      // value = level-0 texel (px, py)
+    pdf = w * w * value / e.imp_total;                          // value = level-0 texel (px, py); imp_total = mips[10][0]
     return {((float)px + ux) / w, ((float)py + uy) / w};      // both axes / width (quirk q10)
 }
 PT_DEV float importance_map_pdf(const EnvRec& e, vec2 uv) {                                                   // Sampling.hlsli:165-174, Common.hlsli:12-15
-    float total = imp_load(e, e.imp_levels - 1, 0, 0);
+    float total = e.imp_total;
     float r = (float)e.imp_res;
     int px = f2i(floorf(uv.x * r) - .5f), py = f2i(floorf(uv.y * r) - .5f);       // UVToPixel: off by one (quirk q9)
     float value = (px < 0 || py < 0) ? 0.f : imp_load(e, 0, (uint32_t)px, (uint32_t)py);

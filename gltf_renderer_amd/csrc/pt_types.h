@@ -137,6 +137,7 @@ struct EnvRec {
     uint32_t level_offset[12];  // float offset of each level
     int32_t imp_res;            // 1024
     int32_t imp_levels;         // 11
+    float imp_total;            // importance[level 10]: the sum of the map (the pdf's normalisation)
     // Copies of levels 1024^2, 256^2, 64^2, 16^2, 4^2 with every 4x4 texel block contiguous (64 B): one cache line feeds two
     // levels of the sampling descent (the in-between level is re-summed from it in the build's order, bit-identically).
     const float* blocked;
