@@ -419,6 +419,40 @@ def test_edge_cases_empty_tiny_and_ragged(R, oracle_lib):
         p.close()
 
 
+def test_tables_larger_than_the_lds_caches(R, oracle_lib):
+    """The shade stage keeps up to 96 materials, 128 instance rows and 32 lights in LDS and falls back to memory beyond that:
+    a scene with 150 instances, 110 materials and 40 lights must still match the oracle (both sides of every limit are hit)."""
+    f32 = np.float32
+    rng = np.random.default_rng(11)
+    s = scenes.test_scene(96, 32)
+    n_extra_mat = 110 - len(s.materials)
+    for k in range(n_extra_mat):
+        s.add_material(scenes.material(base_color_factor=tuple(rng.uniform(0.2, 1.0, 3)) + (1.0,), roughness_factor=float(rng.uniform(0.2, 1.0)),
+                                       metalness_factor=float(rng.uniform(0.0, 1.0))))
+    for k in range(150 - len(s.instances)):
+        c = np.array([rng.uniform(-2.5, 2.5), rng.uniform(-1.0, 3.0), rng.uniform(0.05, 2.5)], f32)
+        a, b = rng.normal(0, 0.25, 3).astype(f32), rng.normal(0, 0.25, 3).astype(f32)
+        n = np.cross(a, b); n = (n / max(np.linalg.norm(n), 1e-6)).astype(f32)
+        m = meshgen.Mesh(np.stack([c, c + a, c + b]).astype(f32), np.array([0, 1, 2]), normals=np.stack([n] * 3), uv0=np.array([[0, 0], [1, 0], [0, 1]], f32))
+        T = np.eye(4); T[:3, 3] = rng.uniform(-0.2, 0.2, 3)
+        s.add_mesh(m, T, int(rng.integers(1, len(s.materials))))
+    while len(s.lights) < 40:
+        s.add_light(abi.LIGHT_POINT, position=tuple(rng.uniform(-3, 3, 3) + np.array([0, 0, 3.0])), color=tuple(rng.uniform(0.3, 1.0, 3)), intensity=float(rng.uniform(2, 10)))
+    assert len(s.instances) >= 150 and len(s.materials) >= 110 and len(s.lights) == 40
+    p = Pair(R, oracle_lib, s)
+    for dbg in (abi.DEBUG_OUTPUT_COLOR, abi.DEBUG_OUTPUT_ROUGHNESS, abi.DEBUG_OUTPUT_VERTEX_NORMAL):
+        st = copy_settings(s.settings); st.debug_output = dbg; st.flags &= ~abi.FLAG_ACCUMULATE; st.use_frame_as_seed = 0; st.seed = 4
+        og, b = p.render(settings=st)
+        err = np.abs(p.r.readback(og)[..., :3] - b[..., :3]).max(axis=2)
+        assert (err > 1e-4).mean() < 0.003, (abi.DEBUG_OUTPUT_NAMES[dbg], float((err > 1e-4).mean()))
+    import oracle.pyoracle as po
+    og, b = p.render(frames=16)
+    assert rel_l2(p.r.tonemap(og), po.tonemap(b)) <= 2e-3
+    sg, so = p.r.stats(), p.o.counters()
+    assert abs(int(sg.rays) - so["rays"]) <= 3e-4 * so["rays"] + 2
+    p.close()
+
+
 # ---- BASELINE-size property tests (no oracle at this size: size-independent identities) --------------------------
 @pytest.fixture(scope="module")
 def sponza(R):
