@@ -211,10 +211,13 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_trace(SceneRec sc
 
 // The reference multiplies the light colour by the shadow transmission BEFORE `if (any(color > 0))` and never evaluates
 // the BSDF of an occluded sample: an occluded sample contributes nothing even when its pending term is NaN.
+// Both pending records are fetched whatever the flags say (the slots always exist): three loads in one round trip instead of
+// the flags first and the records behind them.
 PT_DEV void apply_pending(const WfBuffers& wf, uint32_t slot, vec3& L) {
     const uint32_t pf = wf.pflags[slot];
-    if (pf & 1u) { float4 p = wf.pend_env[slot]; if (p.w > 0.0f) L += v3(p.x, p.y, p.z) * p.w; }
-    if (pf & 2u) { float4 p = wf.pend_light[slot]; if (p.w > 0.0f) L += v3(p.x, p.y, p.z) * p.w; }
+    const float4 pe = wf.pend_env[slot], pl = wf.pend_light[slot];
+    if ((pf & 1u) && pe.w > 0.0f) L += v3(pe.x, pe.y, pe.z) * pe.w;
+    if ((pf & 2u) && pl.w > 0.0f) L += v3(pl.x, pl.y, pl.z) * pl.w;
 }
 
 #ifndef PT_SHADE_WAVES
