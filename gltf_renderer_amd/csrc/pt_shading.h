@@ -803,15 +803,21 @@ PT_DEV vec3 cube_texel(const uint16_t* cube, int n, int face, int i, int j) {
     const uint2 q = *(const uint2*)(cube + (((size_t)face * n + j) * n + i) * 4);     // 8-B RGBA16F texel
     return {half_bits_to_float((uint16_t)(q.x & 0xffff)), half_bits_to_float((uint16_t)(q.x >> 16)), half_bits_to_float((uint16_t)(q.y & 0xffff))};
 }
-PT_DEV vec3 cube_tap(const uint16_t* cube, int n, int face, int i, int j) {
-    if (i >= 0 && i < n && j >= 0 && j < n) return cube_texel(cube, n, face, i, j);
-    // seamless edge: re-project the tap's direction onto the neighbouring face, point fetch there
-    vec3 d = cubemap_to_direction(face, ((float)i + 0.5f) / (float)n, ((float)j + 0.5f) / (float)n);
-    int f2; float u, v;
-    dir_to_face(d, f2, u, v);
-    int ii = (int)floorf(u * (float)n), jj = (int)floorf(v * (float)n);
-    ii = min(max(ii, 0), n - 1); jj = min(max(jj, 0), n - 1);
-    return cube_texel(cube, n, f2, ii, jj);
+// Texel a bilinear tap reads: (i, j) on `face`, or -- off the face's edge -- the texel that the tap's direction lands on on the
+// neighbouring face (seamless filtering by re-projection, point fetch there).  Address only: the four fetches of a sample are
+// issued together afterwards.
+PT_DEV size_t cube_tap_index(int n, int face, int i, int j) {
+    if (!(i >= 0 && i < n && j >= 0 && j < n)) {
+        vec3 d = cubemap_to_direction(face, ((float)i + 0.5f) / (float)n, ((float)j + 0.5f) / (float)n);
+        float u, v;
+        dir_to_face(d, face, u, v);
+        i = (int)floorf(u * (float)n); j = (int)floorf(v * (float)n);
+        i = min(max(i, 0), n - 1); j = min(max(j, 0), n - 1);
+    }
+    return ((size_t)face * n + j) * n + i;
+}
+PT_DEV vec3 cube_unpack(uint2 q) {                                       // 8-B RGBA16F texel
+    return {half_bits_to_float((uint16_t)(q.x & 0xffff)), half_bits_to_float((uint16_t)(q.x >> 16)), half_bits_to_float((uint16_t)(q.y & 0xffff))};
 }
 // TextureCube.SampleLevel(linear, dir, 0) (PathTracer.lib.hlsl:700,1042)
 PT_DEV vec3 sample_cube(const uint16_t* cube, int n, vec3 d) {
@@ -823,8 +829,11 @@ PT_DEV vec3 sample_cube(const uint16_t* cube, int n, vec3 d) {
     float fx = x - fx0, fy = y - fy0;
     int i0 = (int)fx0, j0 = (int)fy0;
     float w00 = (1 - fx) * (1 - fy), w10 = fx * (1 - fy), w01 = (1 - fx) * fy, w11 = fx * fy;
-    return cube_tap(cube, n, face, i0, j0) * w00 + cube_tap(cube, n, face, i0 + 1, j0) * w10 +
-           cube_tap(cube, n, face, i0, j0 + 1) * w01 + cube_tap(cube, n, face, i0 + 1, j0 + 1) * w11;
+    const size_t a00 = cube_tap_index(n, face, i0, j0), a10 = cube_tap_index(n, face, i0 + 1, j0);
+    const size_t a01 = cube_tap_index(n, face, i0, j0 + 1), a11 = cube_tap_index(n, face, i0 + 1, j0 + 1);
+    const uint2* texels = (const uint2*)cube;
+    const uint2 q00 = gload_u2(texels + a00), q10 = gload_u2(texels + a10), q01 = gload_u2(texels + a01), q11 = gload_u2(texels + a11);
+    return cube_unpack(q00) * w00 + cube_unpack(q10) * w10 + cube_unpack(q01) * w01 + cube_unpack(q11) * w11;
 }
 PT_DEV float imp_load(const EnvRec& e, int level, uint32_t x, uint32_t y) {
     uint32_t n = (uint32_t)e.imp_res >> level;
