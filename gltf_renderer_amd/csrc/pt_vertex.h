@@ -232,7 +232,7 @@ PT_DEV Ray camera_ray(const FrameConstants& fc, uint32_t seed, uint32_t px, uint
 
 // RayGeneration epilogue :760-785
 // `accumulated` = frames already in the output when this sample is blended (SceneConstants.accumulated_frames).
-PT_DEV void write_pixel(const FrameConstants& fc, int accumulated, float4* __restrict__ output, uint32_t px, uint32_t py, vec3 L) {
+PT_DEV vec3 sanitize_sample(const FrameConstants& fc, vec3 L) {
     const uint32_t flags = fc.flags;
     if (any_nan(L)) L = (flags & PT_FLAG_SHOW_NAN) ? v3(1, 0, 0) : v3(0);
     if (any_inf(L)) L = (flags & PT_FLAG_SHOW_INF) ? v3(1, 0, 0) : v3(0);
@@ -240,12 +240,18 @@ PT_DEV void write_pixel(const FrameConstants& fc, int accumulated, float4* __res
         float lum = luminance(L);
         if (lum > fc.luminance_clamp) L *= fc.luminance_clamp / lum;
     }
+    return L;
+}
+// the running mean: `h` is the pixel with `accumulated` frames in it
+PT_DEV float4 blend_sample(float4 h, int accumulated, vec3 L) {
+    float blend = 1.0f / ((float)accumulated + 1.0f);
+    return make_float4(h.x + blend * (L.x - h.x), h.y + blend * (L.y - h.y), h.z + blend * (L.z - h.z), h.w + blend * (1.0f - h.w));
+}
+PT_DEV void write_pixel(const FrameConstants& fc, int accumulated, float4* __restrict__ output, uint32_t px, uint32_t py, vec3 L) {
+    L = sanitize_sample(fc, L);
     float4* outp = output + ((size_t)py * fc.res_x + px);
-    if ((flags & PT_FLAG_ACCUMULATE) && accumulated != 0) {
-        float4 h = *outp;
-        float blend = 1.0f / ((float)accumulated + 1.0f);
-        *outp = make_float4(h.x + blend * (L.x - h.x), h.y + blend * (L.y - h.y), h.z + blend * (L.z - h.z), h.w + blend * (1.0f - h.w));
-    } else *outp = make_float4(L.x, L.y, L.z, 1.0f);
+    if ((fc.flags & PT_FLAG_ACCUMULATE) && accumulated != 0) *outp = blend_sample(*outp, accumulated, L);
+    else *outp = make_float4(L.x, L.y, L.z, 1.0f);
 }
 
 // tile-sharded pixel of a (rank-local) slot: slot -> (tile of this rank, lane in tile), one wave64 per 8x8 quadrant

@@ -326,14 +326,22 @@ __global__ __launch_bounds__(kBlock) void k_wf_resolve(FrameConstants fc, WfBuff
     const uint32_t pslot = blockIdx.x * kBlock + threadIdx.x;       // pixel slot; its samples sit pixel_slots apart
     uint32_t px, py;
     if (pslot >= fc.pixel_slots || !slot_pixel(fc, pslot, px, py)) return;
-    // the samples of a batch are blended in sample order, exactly as consecutive PathtraceScene calls would (running mean)
+    // the samples of a batch are blended in sample order, exactly as consecutive PathtraceScene calls would (running mean); the
+    // pixel stays in registers between them: one read and one write of the image however many samples the batch has
+    float4* outp = output + ((size_t)py * fc.res_x + px);
+    const bool accumulate = (fc.flags & PT_FLAG_ACCUMULATE) != 0;
+    float4 pixel = make_float4(0, 0, 0, 0);
+    if (accumulate && fc.accumulated_frames != 0) pixel = *outp;
     for (uint32_t k = 0; k < fc.spp; k++) {
         const uint32_t slot = k * fc.pixel_slots + pslot;
         float4 Lq = wf.L[slot];
         vec3 L = v3(Lq.x, Lq.y, Lq.z);
         apply_pending(wf, slot, L);
-        write_pixel(fc, fc.accumulated_frames + (int)k, output, px, py, L);
+        L = sanitize_sample(fc, L);
+        const int accumulated = fc.accumulated_frames + (int)k;
+        pixel = (accumulate && accumulated != 0) ? blend_sample(pixel, accumulated, L) : make_float4(L.x, L.y, L.z, 1.0f);
     }
+    *outp = pixel;
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
