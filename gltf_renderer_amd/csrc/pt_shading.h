@@ -183,9 +183,16 @@ PT_DEV vec4 sample_slot(const SceneRec& sc, const RMat* m, int slot, const vec2 
 // ---------------------------------------------------------------- vertex fetch (PathTracer.lib.hlsl:176-302)
 // The three vertices of a hit triangle from its 128-B shading packet (pt_types.h ShadePacket: one cache line, 8 x dwordx4).
 struct PacketVerts { vec3 p[3]; uint32_t ts[3]; float2 uv0[3], uv1[3]; uint2 col[3]; uint32_t inst; };
-PT_DEV PacketVerts load_shade_packet(const ShadePacket* pk) {
+struct RawPacket { float4 r[8]; };                          // the eight loads, so that a caller can issue them ahead of their use
+PT_DEV RawPacket load_shade_packet_raw(const ShadePacket* pk) {
     const float4* q = (const float4*)pk;
-    const float4 r[8] = {q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]};
+    RawPacket p;
+#pragma unroll
+    for (int k = 0; k < 8; k++) p.r[k] = q[k];
+    return p;
+}
+PT_DEV PacketVerts unpack_shade_packet(const RawPacket& raw) {
+    const float4* r = raw.r;
     auto f = [&](int i) { const float4 v = r[i >> 2]; return (i & 3) == 0 ? v.x : ((i & 3) == 1 ? v.y : ((i & 3) == 2 ? v.z : v.w)); };
     PacketVerts o;
 #pragma unroll
@@ -200,6 +207,7 @@ PT_DEV PacketVerts load_shade_packet(const ShadePacket* pk) {
     o.inst = __float_as_uint(f(30));
     return o;
 }
+PT_DEV PacketVerts load_shade_packet(const ShadePacket* pk) { return unpack_shade_packet(load_shade_packet_raw(pk)); }
 PT_DEV vec4 fetch_vertex_color(bool present, const PacketVerts& pv, vec3 w) {                         // :229-242
     if (!present) return {1, 1, 1, 1};
     const uint2 q0 = pv.col[0], q1 = pv.col[1], q2 = pv.col[2];

@@ -51,15 +51,17 @@ extern __device__ unsigned long long pt_timing[8];
 #define PT_TICK(K)
 #define PT_TICK_FLUSH()
 #endif
+// `packet`: the hit triangle's shading packet (load_shade_packet_raw(sc.shade + hit.tri)), fetched by the caller so that it can be
+// in flight together with the caller's own fetches.
 PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint32_t seed, uint32_t px, uint32_t py, const Ray& ray, const HitRec& hit,
-                              PathState& ps, Followups& fu, unsigned& taps) {
+                              const RawPacket& packet, PathState& ps, Followups& fu, unsigned& taps) {
     const uint32_t flags = fc.flags;
     fu.add = v3(0); fu.overwrite = false; fu.counted_shadow = 0;
     fu.q_env = fu.q_light = fu.q_bounce = false;
 #ifdef PT_TIMING
     unsigned long long _sec[7] = {0, 0, 0, 0, 0, 0, 0}, _t = __builtin_readcyclecounter();
 #endif
-    const PacketVerts pv = load_shade_packet(sc.shade + hit.tri);     // one 128-B line: the three vertices and the instance row
+    const PacketVerts pv = unpack_shade_packet(packet);               // one 128-B line: the three vertices and the instance id
     const ShadeInst inst = load_shade_inst(sc, pv.inst);
     const RMat* mat = sc.rmats + inst.material_id;
     const MatHeader mh = material_header(sc, inst.material_id);

@@ -255,6 +255,9 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
             slot = __float_as_uint(d.w);
             Ray ray;
             ray.o = v3(o.x, o.y, o.z); ray.tmin = 0; ray.d = v3(d.x, d.y, d.z); ray.tmax = o.w;
+            // the hit's shading packet depends on the queue entry only, like the path state below: one round trip for both
+            const uint32_t hb = __float_as_uint(h.w);
+            const RawPacket packet = load_shade_packet_raw(sc.shade + (hb == kMissTri ? 0u : (hb & 0x7fffffffu)));
             const float4 bp = wf.beta_pdf[slot], tm = wf.thr_misc[slot];
             const uint32_t misc = __float_as_uint(tm.w);
             ps.beta = v3(bp.x, bp.y, bp.z); ps.prev_pdf = bp.w; ps.thr = v3(tm.x, tm.y, tm.z);
@@ -263,7 +266,6 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
             vec3 L = v3(Lq.x, Lq.y, Lq.z);
             apply_pending(wf, slot, L);
             uint32_t pf = 0;
-            const uint32_t hb = __float_as_uint(h.w);
             if (hb == kMissTri) L += shade_miss(sc, fc, ray.d, ps);
             else {
                 HitRec hit;
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
                 uint32_t px, py;
                 slot_pixel(fc, slot, px, py);
                 n_hits++;
-                const bool done = shade_closest_hit(sc, fc, sample_seed(fc, slot_sample(fc, slot)), px, py, ray, hit, ps, fu, st.taps);
+                const bool done = shade_closest_hit(sc, fc, sample_seed(fc, slot_sample(fc, slot)), px, py, ray, hit, packet, ps, fu, st.taps);
                 if (fu.overwrite) L = v3(0);
                 L += fu.add;
                 n_shadow += fu.counted_shadow;
