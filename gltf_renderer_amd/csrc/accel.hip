@@ -303,12 +303,13 @@ __global__ __launch_bounds__(256) void k_fit(const SegBox* __restrict__ T, uint3
     seg_query(T, P, r.f1, r.k1, n.lo1, n.hi1);
 }
 
-// Writes one 64-B wide node: the children's boxes on the 8-bit grid of the node's own box (pt_types.h Bvh4Node).  Conservative:
-// every lo is rounded down and every hi up, and each is checked against bvh_dequant, the expression the traversal evaluates.
+// Writes one wide node: the children's boxes on the 8-bit grid of the node's own box (pt_types.h Bvh4Node).  Conservative: every
+// lo is rounded down and every hi up, and each is checked against bvh_dequant, the expression the traversal evaluates.
 __device__ void wide_write(Bvh4Node* dst, const float (*lo)[3], const float (*hi)[3], const int32_t* ref, int cnt) {
-    uint32_t word[16];
-    uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0}, exps = 0;
+    constexpr int W = kBvhWidth, QW = W / 4;               // QW words per bound (byte k & 3 of word k >> 2 = child k)
+    uint32_t qlo[3][QW], qhi[3][QW], exps = 0, origin[3];
     for (int a = 0; a < 3; a++) {
+        for (int q = 0; q < QW; q++) qlo[a][q] = qhi[a][q] = 0;
         float p = lo[0][a], top = hi[0][a];
         for (int k = 1; k < cnt; k++) { p = fminf(p, lo[k][a]); top = fmaxf(top, hi[k][a]); }
         // smallest power-of-two step whose 255th plane reaches the far side
@@ -321,22 +322,29 @@ __device__ void wide_write(Bvh4Node* dst, const float (*lo)[3], const float (*hi
             ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql); qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
             while (ql > 0 && bvh_dequant((uint32_t)ql, step, p) > lo[k][a]) ql--;
             while (qh < 255 && bvh_dequant((uint32_t)qh, step, p) < hi[k][a]) qh++;
-            qlo[a] |= (uint32_t)ql << (8 * k); qhi[a] |= (uint32_t)qh << (8 * k);
+            qlo[a][k >> 2] |= (uint32_t)ql << (8 * (k & 3)); qhi[a][k >> 2] |= (uint32_t)qh << (8 * (k & 3));
         }
-        word[a] = __float_as_uint(p);
+        origin[a] = __float_as_uint(p);
         exps |= e << (8 * a);
     }
-    word[3] = exps;
-    for (int k = 0; k < 4; k++) word[4 + k] = (uint32_t)(k < cnt ? ref[k] : kEmptyChild);
-    word[8] = qlo[0]; word[9] = qhi[0]; word[10] = qlo[1]; word[11] = qhi[1]; word[12] = qlo[2]; word[13] = qhi[2]; word[14] = word[15] = 0;
+    uint32_t word[kNodeFloat4 * 4];
+    for (int k = 0; k < kNodeFloat4 * 4; k++) word[k] = 0;
+    word[0] = origin[0]; word[1] = origin[1]; word[2] = origin[2]; word[3] = exps;
+    for (int k = 0; k < W; k++) word[4 + k] = (uint32_t)(k < cnt ? ref[k] : kEmptyChild);
+    int at = 4 + W;
+    if (W == 4) {                                           // [qlox qhix qloy qhiy] [qloz qhiz 0 0]
+        word[at + 0] = qlo[0][0]; word[at + 1] = qhi[0][0]; word[at + 2] = qlo[1][0]; word[at + 3] = qhi[1][0]; word[at + 4] = qlo[2][0]; word[at + 5] = qhi[2][0];
+    } else {                                                // one dwordx4 per axis: [qlo 0-3, qlo 4-7, qhi 0-3, qhi 4-7]
+        for (int a = 0; a < 3; a++) { word[at + 4 * a + 0] = qlo[a][0]; word[at + 4 * a + 1] = qlo[a][QW - 1]; word[at + 4 * a + 2] = qhi[a][0]; word[at + 4 * a + 3] = qhi[a][QW - 1]; }
+    }
     uint4* d = (uint4*)dst;
 #pragma unroll
-    for (int q = 0; q < 4; q++) d[q] = make_uint4(word[4 * q], word[4 * q + 1], word[4 * q + 2], word[4 * q + 3]);
+    for (int q = 0; q < kNodeFloat4; q++) d[q] = make_uint4(word[4 * q], word[4 * q + 1], word[4 * q + 2], word[4 * q + 3]);
 }
 
-// 6. collapse to 4-wide, greedily by surface area, level by level of the WIDE tree, top down.  A frontier entry is a binary node
+// 6. collapse to wide nodes (kBvhWidth children), greedily by surface area, level by level of the WIDE tree, top down.  A frontier entry is a binary node
 //    that becomes a wide node; it starts with its two children and keeps opening the inner child with the largest box until it
-//    holds four children or only leaves.  Compared with "keep every even level of the binary tree" this fills the slots (about
+//    holds kBvhWidth children or only leaves.  Compared with "keep every even level of the binary tree" this fills the slots (about
 //    3.0 -> 3.6 children per node on the Sponza-class scene), so the tree is shallower and a ray visits fewer nodes.
 //    counters[0]: wide nodes allocated so far; counters[1 + L]: size of level L's frontier.
 __device__ void collapse_one(const BvhNode* __restrict__ nodes2, uint32_t binary_node, uint32_t wide_index, uint32_t level,
@@ -351,11 +359,13 @@ __device__ void collapse_one(const BvhNode* __restrict__ nodes2, uint32_t binary
     };
     const BvhNode& n = nodes2[binary_node];
     const ChildRanges nr = child_ranges(n);
-    int32_t ref[4] = {child_ref(n.child0, nr.f0, nr.k0), child_ref(n.child1, nr.f1, nr.k1), kEmptyChild, kEmptyChild};
-    float lo[4][3], hi[4][3];
+    int32_t ref[kBvhWidth];
+    for (int k = 2; k < kBvhWidth; k++) ref[k] = kEmptyChild;
+    ref[0] = child_ref(n.child0, nr.f0, nr.k0); ref[1] = child_ref(n.child1, nr.f1, nr.k1);
+    float lo[kBvhWidth][3], hi[kBvhWidth][3];
     for (int a = 0; a < 3; a++) { lo[0][a] = n.lo0[a]; hi[0][a] = n.hi0[a]; lo[1][a] = n.lo1[a]; hi[1][a] = n.hi1[a]; }
     int cnt = 2;
-    while (cnt < 4) {
+    while (cnt < kBvhWidth) {
         int pick = -1;
         float best = -1.0f;
         for (int k = 0; k < cnt; k++) {
@@ -528,7 +538,7 @@ hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const Instan
         for (int j = 0; j < 8; j++, level++, cur ^= 1u) {
             hipLaunchKernelGGL(k_collapse_level, dim3((bound + 255) / 256), dim3(256), 0, stream, s.nodes2, fr[cur], wi[cur], level, fr[cur ^ 1u], wi[cur ^ 1u],
                                s.collapse_counters, d_nodes);
-            bound = bound > n_nodes / 4 ? n_nodes : bound * 4;
+            bound = bound > n_nodes / kBvhWidth ? n_nodes : bound * kBvhWidth;
         }
         uint32_t next = 0;
         if ((e = hipMemcpyAsync(&next, s.collapse_counters + 1 + level, 4, hipMemcpyDeviceToHost, stream))) return e;

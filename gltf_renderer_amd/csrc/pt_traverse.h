@@ -98,6 +98,69 @@ PT_DEV void trav_pop(Trav& t, const int* lds_stack, const int* spill) {
 
 #define PT_CSWAP(a, b) { uint32_t _lo = min(a, b), _hi = max(a, b); a = _lo; b = _hi; }
 
+#if PT_BVH_WIDTH == 8
+// One inner-node step over an 8-wide node (pt_types.h): six dwordx4 loads, eight slab tests.  Each hit child becomes a 64-bit
+// (entry distance, child reference) pair; closest-hit rays sort the pairs with a 19-exchange network and visit near to far.
+// On exit t.cur is the nearest hit child, or the popped entry, or kTravDone.
+#define PT_CSWAP64(a, b) { const unsigned long long _lo = a < b ? a : b, _hi = a < b ? b : a; a = _lo; b = _hi; }
+template <bool COUNT, bool ORDERED = true>
+PT_DEV void trav_node_step(Trav& t, const SceneRec& sc, int* lds_stack, int* spill, LaneStats& st) {
+    const float4* np = (const float4*)sc.nodes + (size_t)t.cur * kNodeFloat4;
+    const float4 hd = np[0], ca = np[1], cb = np[2], qx = np[3], qy = np[4], qz = np[5];
+    if (COUNT) st.nodes++;
+    const float limit = t.all_candidates ? t.tmax : t.best.t;
+    const uint32_t ex = __float_as_uint(hd.w);
+    const float sx = bvh_step(ex & 0xffu), sy = bvh_step((ex >> 8) & 0xffu), sz = bvh_step((ex >> 16) & 0xffu);
+    const int c[8] = {__float_as_int(ca.x), __float_as_int(ca.y), __float_as_int(ca.z), __float_as_int(ca.w),
+                      __float_as_int(cb.x), __float_as_int(cb.y), __float_as_int(cb.z), __float_as_int(cb.w)};
+    // words: q?.x = lo of children 0-3, q?.y = lo of 4-7, q?.z = hi of 0-3, q?.w = hi of 4-7 (byte k & 3 = child k)
+    const uint32_t lx[2] = {__float_as_uint(qx.x), __float_as_uint(qx.y)}, hx[2] = {__float_as_uint(qx.z), __float_as_uint(qx.w)};
+    const uint32_t ly[2] = {__float_as_uint(qy.x), __float_as_uint(qy.y)}, hy[2] = {__float_as_uint(qy.z), __float_as_uint(qy.w)};
+    const uint32_t lz[2] = {__float_as_uint(qz.x), __float_as_uint(qz.y)}, hz[2] = {__float_as_uint(qz.z), __float_as_uint(qz.w)};
+    unsigned long long e[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int w = k >> 2, sh = 8 * (k & 3);
+        const float LX = bvh_dequant((lx[w] >> sh) & 0xffu, sx, hd.x), HX = bvh_dequant((hx[w] >> sh) & 0xffu, sx, hd.x);
+        const float LY = bvh_dequant((ly[w] >> sh) & 0xffu, sy, hd.y), HY = bvh_dequant((hy[w] >> sh) & 0xffu, sy, hd.y);
+        const float LZ = bvh_dequant((lz[w] >> sh) & 0xffu, sz, hd.z), HZ = bvh_dequant((hz[w] >> sh) & 0xffu, sz, hd.z);
+        const float a0 = LX * t.inv.x - t.ood.x, b0 = HX * t.inv.x - t.ood.x, a1 = LY * t.inv.y - t.ood.y, b1 = HY * t.inv.y - t.ood.y;
+        const float a2 = LZ * t.inv.z - t.ood.z, b2 = HZ * t.inv.z - t.ood.z;
+        const float tn = fmaxf(fmaxf(fminf(a0, b0), fminf(a1, b1)), fmaxf(fminf(a2, b2), t.tmin));
+        const float tx = fminf(fminf(fmaxf(a0, b0), fmaxf(a1, b1)), fminf(fmaxf(a2, b2), limit)) * 1.0000004f;
+        const bool hit = tn <= tx && c[k] != kEmptyChild;
+        // tn >= 0, so its bit pattern orders like the float; a miss sorts behind every hit
+        e[k] = hit ? (((unsigned long long)__float_as_uint(tn) << 32) | (uint32_t)c[k]) : ~0ull;
+    }
+    // a step pushes at most seven entries: if no active lane is within seven of the LDS part's end, every push is a plain ds_write
+    const bool shallow = __ballot(t.sp + 7 > kStackLds) == 0;
+    if (!ORDERED) {
+        // occlusion rays accept any hit: visiting order is irrelevant, skip the sort
+        int next = kTravDone;
+#define PT_PUSH_UNORDERED(F)                                                                                                        \
+        _Pragma("unroll") for (int k = 0; k < 8; k++)                                                                               \
+            if (e[k] != ~0ull) { if (next != kTravDone) trav_push<F>(t, lds_stack, spill, (int)(uint32_t)e[k], st); else next = (int)(uint32_t)e[k]; }
+        if (shallow) { PT_PUSH_UNORDERED(true) } else { PT_PUSH_UNORDERED(false) }
+#undef PT_PUSH_UNORDERED
+        if (next != kTravDone) t.cur = next; else trav_pop(t, lds_stack, spill);
+        return;
+    }
+    // Batcher's odd-even merge sort for eight: misses (~0) sink to the end
+    PT_CSWAP64(e[0], e[1]) PT_CSWAP64(e[2], e[3]) PT_CSWAP64(e[4], e[5]) PT_CSWAP64(e[6], e[7])
+    PT_CSWAP64(e[0], e[2]) PT_CSWAP64(e[1], e[3]) PT_CSWAP64(e[4], e[6]) PT_CSWAP64(e[5], e[7])
+    PT_CSWAP64(e[1], e[2]) PT_CSWAP64(e[5], e[6])
+    PT_CSWAP64(e[0], e[4]) PT_CSWAP64(e[1], e[5]) PT_CSWAP64(e[2], e[6]) PT_CSWAP64(e[3], e[7])
+    PT_CSWAP64(e[2], e[4]) PT_CSWAP64(e[3], e[5])
+    PT_CSWAP64(e[1], e[2]) PT_CSWAP64(e[3], e[4]) PT_CSWAP64(e[5], e[6])
+    if (e[0] != ~0ull) {
+#define PT_PUSH_ORDERED(F)                                                                                                          \
+        _Pragma("unroll") for (int k = 7; k >= 1; k--) if (e[k] != ~0ull) trav_push<F>(t, lds_stack, spill, (int)(uint32_t)e[k], st);
+        if (shallow) { PT_PUSH_ORDERED(true) } else { PT_PUSH_ORDERED(false) }
+#undef PT_PUSH_ORDERED
+        t.cur = (int)(uint32_t)e[0];
+    } else trav_pop(t, lds_stack, spill);
+}
+#else
 // One inner-node step: t.cur >= 0 on entry; on exit t.cur is the nearest hit child, or the popped entry, or kTravDone.
 template <bool COUNT, bool ORDERED = true>
 PT_DEV void trav_node_step(Trav& t, const SceneRec& sc, int* lds_stack, int* spill, LaneStats& st) {
@@ -158,6 +221,7 @@ PT_DEV void trav_node_step(Trav& t, const SceneRec& sc, int* lds_stack, int* spi
         t.cur = child_of(key[0]);
     } else trav_pop(t, lds_stack, spill);
 }
+#endif
 
 // One leaf step: t.cur = leaf reference (1..kLeafMax contiguous triangles) on entry; on exit the popped entry or kTravDone.
 template <bool COUNT>

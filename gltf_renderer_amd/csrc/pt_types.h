@@ -87,6 +87,14 @@ static_assert(sizeof(BvhNode) == 64, "BvhNode");
 // Quantisation is conservative (lo rounded down, hi rounded up, checked with the very fma the traversal uses), so a ray enters a
 // superset of the children it would enter with exact boxes and finds the same hits.
 // child >= 0: wide node index; child < 0: leaf reference (below); kEmptyChild: unused slot (never entered).
+#ifndef PT_BVH_WIDTH
+#define PT_BVH_WIDTH 4          // children per wide node: 4 (64-B node, 4 loads per step) or 8 (96-B node, 6 loads per step).  Measured:
+                                // 8-wide takes 10.2 node steps per ray instead of 15.4 with the same loads per ray and is 8.5 % SLOWER
+                                // (4146 against 4530 Mrays/s: eight slab tests and a 19-exchange sort per step are no longer free)
+#endif
+constexpr int kBvhWidth = PT_BVH_WIDTH;
+static_assert(kBvhWidth == 4 || kBvhWidth == 8, "PT_BVH_WIDTH");
+#if PT_BVH_WIDTH == 4
 struct __attribute__((aligned(64))) Bvh4Node {
     float origin[3];                // lo corner of the union of the children
     uint8_t exp[3], _e;             // biased exponents of the per-axis grid step
@@ -96,6 +104,18 @@ struct __attribute__((aligned(64))) Bvh4Node {
     uint32_t _pad[2];
 };
 static_assert(sizeof(Bvh4Node) == 64, "Bvh4Node");
+#else
+// 8-wide: the same encoding with eight children, 96 B = six dwordx4 loads.  A ray takes about half as many node steps, and a
+// step is one dependent round trip to memory whatever it fetches.
+struct __attribute__((aligned(16))) Bvh4Node {
+    float origin[3];
+    uint8_t exp[3], _e;
+    int32_t child[8];
+    uint8_t qlox[8], qhix[8], qloy[8], qhiy[8], qloz[8], qhiz[8];     // byte k & 3 of word k >> 2 of each bound = child k
+};
+static_assert(sizeof(Bvh4Node) == 96, "Bvh4Node");
+#endif
+constexpr int kNodeFloat4 = (int)(sizeof(Bvh4Node) / 16);
 constexpr int32_t kEmptyChild = 0x7fffffff;
 // the plane a quantised coordinate stands for; build and traversal must use this one expression
 __host__ __device__ __forceinline__ float bvh_dequant(uint32_t q, float step, float origin) { return __builtin_fmaf((float)q, step, origin); }
