@@ -89,8 +89,8 @@ static_assert(sizeof(BvhNode) == 64, "BvhNode");
 // child >= 0: wide node index; child < 0: leaf reference (below); kEmptyChild: unused slot (never entered).
 #ifndef PT_BVH_WIDTH
 #define PT_BVH_WIDTH 4          // children per wide node: 4 (64-B node, 4 loads per step) or 8 (96-B node, 6 loads per step).  Measured:
-                                // 8-wide takes 10.2 node steps per ray instead of 15.4 with the same loads per ray and is 8.5 % SLOWER
-                                // (4146 against 4530 Mrays/s: eight slab tests and a 19-exchange sort per step are no longer free)
+                                // 8-wide takes 10.4 node steps per ray instead of 15.4 with the same loads per ray and is 7 % SLOWER
+                                // (4200 against 4530 Mrays/s: eight dequantised slab tests per step are no longer free)
 #endif
 constexpr int kBvhWidth = PT_BVH_WIDTH;
 static_assert(kBvhWidth == 4 || kBvhWidth == 8, "PT_BVH_WIDTH");
