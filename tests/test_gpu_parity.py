@@ -185,7 +185,7 @@ def test_gpu_lbvh_closest_hits_match_bruteforce(R, oracle_lib):
         err = np.abs(r.readback(og)[..., :3] - b[..., :3]).max(axis=2)
         assert (err > 1e-4).mean() < 0.002
     st = r.stats()
-    # 4-wide nodes collapsed from the n-1 binary LBVH nodes: every other level is kept
+    # wide nodes collapsed greedily from the n-1 binary LBVH nodes
     assert st.bvh_triangles == s.triangles and s.triangles // 32 <= st.bvh_nodes <= s.triangles - 1      # wide nodes (<= 8 children) over leaves of <= 3 triangles
     r.close(); o.close()
 
