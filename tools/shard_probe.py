@@ -21,7 +21,7 @@ st = abi.PtSettings.from_buffer_copy(bytes(s.settings))
 st.reset = 1
 K = 12
 for n in (1, 2, 4, 8):
-    for spp in sorted({1, n}):
+    for spp in sorted({1, n, min(8 * n, 64)}):          # 8 x N is what bench.py gives each rank of an N-GPU run
         r.set_samples_per_trace(spp)
         for f in range(2):
             r.trace(st, s.execute_params(frame=f * spp, tile_rank=0, tile_rank_count=n, env_handle=h["env"]), out)
