@@ -56,7 +56,7 @@ struct pt_ctx {
     void* d_bones = nullptr; size_t bones_cap = 0;
     void* d_workspace = nullptr; size_t workspace_cap = 0;     // wavefront ray / hit / path-state arrays
     int kernel_mode = PT_MODE_WAVEFRONT;
-    int stage_blocks = 1536;      // 256 CUs x 6 resident 256-thread workgroups of the trace stages (LDS- and VGPR-limited)
+    int stage_blocks = 0;         // workgroups per stage launch; 0 = by the size of the launch (stage_blocks_for)
     hipEvent_t ev_trace[2] = {nullptr, nullptr}, ev_accel[2] = {nullptr, nullptr}, ev_skin[2] = {nullptr, nullptr};
     bool have_trace = false, have_accel = false, have_skin = false;
     int bounce_limit = PT_REFERENCE_MAX_BOUNCES;
@@ -147,6 +147,13 @@ size_t format_stride(int f) {
         default: return 0;
     }
 }
+
+// Workgroups per stage launch.  256 CUs hold 6 resident 256-thread workgroups of the trace stages (LDS- and VGPR-limited): 1536
+// for a launch that has the rays to feed them.  A small launch (a 1/8 tile shard of one sample) is better off with fewer
+// persistent workgroups -- each stages its LDS tables and polls the shard queues whether it gets rays or not.  Measured
+// (tools/stage_blocks_probe.py, Mrays/s at 512 / 768 / 1536 workgroups): 259 k slots 1121 / 1099 / 1065, 518 k slots
+// 1632 / 1685 / 1551, 2.07 M slots 2500 / 2697 / 3149.
+int stage_blocks_for(size_t slots) { return slots >= 1200000 ? 1536 : (slots >= 400000 ? 768 : 512); }
 
 }  // namespace
 
@@ -260,14 +267,15 @@ public:
             } else {
                 fc.spp = (uint32_t)batch;
                 if ((unsigned long long)fc.pixel_slots * fc.spp > 0x7fffffffull) return ctx->fail(PT_ERR_CAPACITY, "sample batch too large for this resolution");
-                size_t need = wavefront_workspace_bytes(fc.pixel_slots * fc.spp, ctx->stage_blocks);
+                const int stage_blocks = ctx->stage_blocks > 0 ? ctx->stage_blocks : stage_blocks_for((size_t)fc.pixel_slots * fc.spp);
+                size_t need = wavefront_workspace_bytes(fc.pixel_slots * fc.spp, stage_blocks);
                 if (need > ctx->workspace_cap) {
                     HIPOK(hipStreamSynchronize(ctx->stream));
                     hipFree(ctx->d_workspace); ctx->d_workspace = nullptr; ctx->workspace_cap = 0;
                     HIPOK(hipMalloc(&ctx->d_workspace, need));
                     ctx->workspace_cap = need;
                 }
-                HIPOK(launch_wavefront(sc, fc, (float4*)ep->output, ctx->d_counters, ctx->counters_enabled, ctx->d_workspace, ctx->stage_blocks, ctx->stream));
+                HIPOK(launch_wavefront(sc, fc, (float4*)ep->output, ctx->d_counters, ctx->counters_enabled, ctx->d_workspace, stage_blocks, ctx->stream));
             }
             HIPOK(hipGetLastError());
             HIPOK(hipEventRecord(ctx->ev_trace[1], ctx->stream));

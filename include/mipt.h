@@ -378,7 +378,8 @@ int pt_set_null_shadow_culling(pt_ctx* ctx, int enable);
 int pt_enable_counters(pt_ctx* ctx, int enable);      /* node / triangle / tap counters (slower) */
 /* Kernel arrangement (same per-vertex code, same results up to fp32 accumulation order): PT_MODE_WAVEFRONT (default) =
  * staged trace / shade / shadow kernels over SoA ray queues in HBM with ballot compaction; PT_MODE_MEGAKERNEL = one
- * lane per pixel-sample for the whole path.  stage_blocks: workgroups per wavefront stage launch (<= 0 keeps the default). */
+ * lane per pixel-sample for the whole path.  stage_blocks: workgroups per wavefront stage launch (<= 0 keeps the current setting; the
+ * initial setting sizes it by the launch: 1536 for a full 1080p frame, fewer for a small tile shard). */
 enum { PT_MODE_WAVEFRONT = 0, PT_MODE_MEGAKERNEL = 1 };
 int pt_set_kernel_mode(pt_ctx* ctx, int mode, int stage_blocks);
 /* Counters accumulate over pt_trace calls since the last pt_reset_stats; the *_ms fields are the
