@@ -235,7 +235,14 @@ class PtStats(C.Structure):
                 ("rays_shadow", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
                 ("closest_hits", C.c_uint64), ("texture_taps", C.c_uint64),
                 ("trace_ms", C.c_float), ("accel_ms", C.c_float), ("skin_ms", C.c_float),
-                ("accumulated_frames", C.c_int32), ("bvh_nodes", C.c_uint32), ("bvh_triangles", C.c_uint32)]
+                ("accumulated_frames", C.c_int32), ("bvh_nodes", C.c_uint32), ("bvh_triangles", C.c_uint32),
+                ("nodes_visited_shadow", C.c_uint64), ("tris_tested_shadow", C.c_uint64), ("stage_ms", C.c_float * 5),
+                ("bvh_stack_need", C.c_uint32), ("accel_builds", C.c_uint32), ("accel_refits", C.c_uint32)]
+
+
+STAGE_NAMES = ("generate", "trace", "shade", "shadow", "resolve")
+EXCHANGE_GATHER, EXCHANGE_REDUCE = 0, 1
+EXCHANGE_ID_BYTES = 128
 
 
 assert C.sizeof(PtSettings) == 64
@@ -246,3 +253,4 @@ assert C.sizeof(PtMeshInstance) == 156
 assert C.sizeof(PtInstanceDesc) == 176
 assert C.sizeof(PtExecuteParams) == 168
 assert C.sizeof(PtBone) == 128
+assert C.sizeof(PtStats) == 136

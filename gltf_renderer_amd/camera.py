@@ -37,6 +37,24 @@ def view_to_clip(aspect, y_fov=math.pi / 2, z_near=0.01, z_far=100.0):
     return perspective_rh_zo(y_fov, aspect, 100000.0, z_near)
 
 
+def ortho_rh_zo(left, right, bottom, top, z_near, z_far):
+    """glm::orthoRH_ZO."""
+    m = np.eye(4)
+    m[0, 0] = 2.0 / (right - left)
+    m[1, 1] = 2.0 / (top - bottom)
+    m[2, 2] = -1.0 / (z_far - z_near)
+    m[0, 3] = -(right + left) / (right - left)
+    m[1, 3] = -(top + bottom) / (top - bottom)
+    m[2, 3] = -z_near / (z_far - z_near)
+    return m
+
+
+def ortho_view_to_clip(x_mag, y_mag, z_near=0.01, z_far=100.0):
+    """Camera::GetViewToClip, orthographic branch (Camera.h:91): orthoRH_ZO(-1/x_mag, 1/x_mag, -1/y_mag, 1/y_mag, z_far, z_near)
+    -- half extents 1/mag (sic) and near/far swapped for reversed Z."""
+    return ortho_rh_zo(-1.0 / x_mag, 1.0 / x_mag, -1.0 / y_mag, 1.0 / y_mag, z_far, z_near)
+
+
 def translate(v):
     m = np.eye(4)
     m[:3, 3] = v

@@ -347,9 +347,11 @@ __device__ void wide_write(Bvh4Node* dst, const float (*lo)[3], const float (*hi
 //    holds kBvhWidth children or only leaves.  Compared with "keep every even level of the binary tree" this fills the slots (about
 //    3.0 -> 3.6 children per node on the Sponza-class scene), so the tree is shallower and a ray visits fewer nodes.
 //    counters[0]: wide nodes allocated so far; counters[1 + L]: size of level L's frontier.
+constexpr int kCollapseMaxLevels = 4096;
+constexpr int kCollapseNeedSlot = kCollapseMaxLevels + 8;       // counters[] slot: the deepest traversal stack any ray can need (entries)
 __device__ void collapse_one(const BvhNode* __restrict__ nodes2, uint32_t binary_node, uint32_t wide_index, uint32_t level,
                              uint32_t* __restrict__ frontier_out, uint32_t* __restrict__ widx_out, uint32_t* __restrict__ counters,
-                             Bvh4Node* __restrict__ out) {
+                             Bvh4Node* __restrict__ out, WideRanges* __restrict__ ranges_out, uint32_t need_in, uint32_t* __restrict__ need_out) {
     // References while collapsing: a binary node index (>= 0) or a leaf reference (< 0).  An inner subtree of at most kLeafMax
     // triangles becomes ONE leaf (its triangles are contiguous): the bottom of a binary tree is full of 2- and 3-triangle
     // subtrees, which as wide nodes would spend a whole node step on two boxes.  Its size follows from the parent's range.
@@ -360,8 +362,11 @@ __device__ void collapse_one(const BvhNode* __restrict__ nodes2, uint32_t binary
     const BvhNode& n = nodes2[binary_node];
     const ChildRanges nr = child_ranges(n);
     int32_t ref[kBvhWidth];
+    WideRanges wr;                                          // the sorted-triangle range under every child: what a refit re-queries
+    for (int k = 0; k < kBvhWidth; k++) { wr.first[k] = 0; wr.count[k] = 0; }
     for (int k = 2; k < kBvhWidth; k++) ref[k] = kEmptyChild;
     ref[0] = child_ref(n.child0, nr.f0, nr.k0); ref[1] = child_ref(n.child1, nr.f1, nr.k1);
+    wr.first[0] = nr.f0; wr.count[0] = nr.k0; wr.first[1] = nr.f1; wr.count[1] = nr.k1;
     float lo[kBvhWidth][3], hi[kBvhWidth][3];
     for (int a = 0; a < 3; a++) { lo[0][a] = n.lo0[a]; hi[0][a] = n.hi0[a]; lo[1][a] = n.lo1[a]; hi[1][a] = n.hi1[a]; }
     int cnt = 2;
@@ -378,6 +383,7 @@ __device__ void collapse_one(const BvhNode* __restrict__ nodes2, uint32_t binary
         const BvhNode& m = nodes2[ref[pick]];
         const ChildRanges mr = child_ranges(m);
         ref[pick] = child_ref(m.child0, mr.f0, mr.k0); ref[cnt] = child_ref(m.child1, mr.f1, mr.k1);
+        wr.first[pick] = mr.f0; wr.count[pick] = mr.k0; wr.first[cnt] = mr.f1; wr.count[cnt] = mr.k1;
         for (int a = 0; a < 3; a++) { lo[pick][a] = m.lo0[a]; hi[pick][a] = m.hi0[a]; lo[cnt][a] = m.lo1[a]; hi[cnt][a] = m.hi1[a]; }
         cnt++;
     }
@@ -398,46 +404,61 @@ __device__ void collapse_one(const BvhNode* __restrict__ nodes2, uint32_t binary
     uint32_t base_f = 0, base_w = 0;
     if ((int)lane == leader && total) { base_f = atomicAdd(counters + 2 + level, total); base_w = atomicAdd(counters + 0, total); }
     base_f = __shfl(base_f, leader, 64); base_w = __shfl(base_w, leader, 64);
+    // Traversal-stack entries a ray can hold below this node: what it held on arrival plus the cnt - 1 siblings it pushes here.
+    // The maximum over all nodes is the stack a ray can ever need; one atomicMax per wave (running maximum up the active lanes,
+    // which are a prefix of the wave).
+    const uint32_t need = need_in + (uint32_t)cnt - 1u;
+    uint32_t run = need;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(run, off, 64);
+        if (lane >= (uint32_t)off) run = max(run, up);
+    }
+    if ((int)lane == last) atomicMax(counters + kCollapseNeedSlot, run);
     uint32_t slot = incl - mine;
     for (int k = 0; k < cnt; k++) {
         if (ref[k] >= 0) {
             frontier_out[base_f + slot] = (uint32_t)ref[k];
             widx_out[base_f + slot] = base_w + slot;
+            need_out[base_f + slot] = need;
             ref[k] = (int32_t)(base_w + slot);
             slot++;
         }
     }
     wide_write(out + wide_index, lo, hi, ref, cnt);
+    ranges_out[wide_index] = wr;
 }
 
-constexpr int kCollapseMaxLevels = 4096;
-__global__ __launch_bounds__(256) void k_collapse_init(uint32_t* __restrict__ frontier, uint32_t* __restrict__ widx, uint32_t* __restrict__ counters) {
+__global__ __launch_bounds__(256) void k_collapse_init(uint32_t* __restrict__ frontier, uint32_t* __restrict__ widx, uint32_t* __restrict__ need,
+                                                       uint32_t* __restrict__ counters) {
     for (int k = threadIdx.x; k < kCollapseMaxLevels + 16; k += 256) counters[k] = k <= 1 ? 1u : 0u;   // one wide node (the root), level 0 holds one entry
-    if (threadIdx.x == 0) { frontier[0] = 0u; widx[0] = 0u; }                                       // binary node 0 -> wide node 0
+    if (threadIdx.x == 0) { frontier[0] = 0u; widx[0] = 0u; need[0] = 0u; }                         // binary node 0 -> wide node 0
 }
 
 // One level per launch (large scenes).  The host launches several levels without looking, with grids sized for the largest
 // frontier the level can have, so a level may well be empty.
 __global__ __launch_bounds__(256) void k_collapse_level(const BvhNode* __restrict__ nodes2, const uint32_t* __restrict__ frontier_in,
                                                         const uint32_t* __restrict__ widx_in, uint32_t level, uint32_t* __restrict__ frontier_out,
-                                                        uint32_t* __restrict__ widx_out, uint32_t* __restrict__ counters, Bvh4Node* __restrict__ out) {
+                                                        uint32_t* __restrict__ widx_out, uint32_t* __restrict__ counters, Bvh4Node* __restrict__ out,
+                                                        WideRanges* __restrict__ ranges_out, const uint32_t* __restrict__ need_in, uint32_t* __restrict__ need_out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= counters[1 + level]) return;
-    collapse_one(nodes2, frontier_in[i], widx_in[i], level, frontier_out, widx_out, counters, out);
+    collapse_one(nodes2, frontier_in[i], widx_in[i], level, frontier_out, widx_out, counters, out, ranges_out, need_in[i], need_out);
 }
 
 // All levels in one launch of ONE workgroup (small scenes: a rebuild per animation frame is launch-bound, and sixteen level
 // launches were 0.22 of its 0.39 ms).  Levels are separated by workgroup barriers; the frontier ping-pongs between fr[0] and fr[1].
 constexpr uint32_t kSmallCollapseNodes = 32768;
 __global__ __launch_bounds__(1024) void k_collapse_small(const BvhNode* __restrict__ nodes2, uint32_t* fr0, uint32_t* wi0, uint32_t* fr1, uint32_t* wi1,
-                                                         uint32_t* counters, Bvh4Node* __restrict__ out) {
+                                                         uint32_t* counters, Bvh4Node* __restrict__ out, WideRanges* __restrict__ ranges_out, uint32_t* nd0, uint32_t* nd1) {
     for (uint32_t level = 0; level < (uint32_t)kCollapseMaxLevels; level++) {
         // (the counters are advanced by agent-scope atomics, which are performed in L2 and leave this CU's L1 copy of the line stale)
         const uint32_t n_in = __hip_atomic_load(counters + 1 + level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (n_in == 0) break;                                        // the same for every lane: no barrier is skipped by some
         uint32_t* fin = (level & 1u) ? fr1 : fr0;  uint32_t* win = (level & 1u) ? wi1 : wi0;
         uint32_t* fout = (level & 1u) ? fr0 : fr1; uint32_t* wout = (level & 1u) ? wi0 : wi1;
-        for (uint32_t i = threadIdx.x; i < n_in; i += blockDim.x) collapse_one(nodes2, fin[i], win[i], level, fout, wout, counters, out);
+        const uint32_t* nin = (level & 1u) ? nd1 : nd0; uint32_t* nout = (level & 1u) ? nd0 : nd1;
+        for (uint32_t i = threadIdx.x; i < n_in; i += blockDim.x) collapse_one(nodes2, fin[i], win[i], level, fout, wout, counters, out, ranges_out, nin[i], nout);
         __threadfence_block();
         __syncthreads();
     }
@@ -446,7 +467,7 @@ __global__ __launch_bounds__(1024) void k_collapse_small(const BvhNode* __restri
 static void free_all(AccelScratch& s) {
     hipFree(s.tris_unsorted); hipFree(s.keys_a); hipFree(s.keys_b); hipFree(s.vals_a); hipFree(s.vals_b);
     hipFree(s.leaf_parent); hipFree(s.node_parent); hipFree(s.seg); hipFree(s.block_bounds); hipFree(s.sort_temp);
-    hipFree(s.nodes2); hipFree(s.kept); hipFree(s.widx); hipFree(s.collapse_counters);
+    hipFree(s.nodes2); hipFree(s.kept); hipFree(s.widx); hipFree(s.collapse_counters); hipFree(s.wide_ranges);
 }
 
 static hipError_t ensure(AccelScratch& s, size_t n) {
@@ -477,6 +498,7 @@ static hipError_t ensure(AccelScratch& s, size_t n) {
     if ((e = hipMalloc(&s.sort_temp, tb))) return e;
     s.sort_temp_bytes = tb;
     if ((e = hipMalloc(&s.collapse_counters, (kCollapseMaxLevels + 16) * 4))) return e;
+    if ((e = hipMalloc(&s.wide_ranges, cap * sizeof(WideRanges)))) return e;
     s.capacity = cap;
     return hipSuccess;
 }
@@ -487,10 +509,23 @@ void accel_scratch_free(AccelScratch& s) {
     s = AccelScratch();
 }
 
+// The segment tree over the sorted triangles' boxes (all levels), from the packets as they stand.
+static void seg_build(AccelScratch& s, const TriPacket* d_tris, uint32_t n_tris, hipStream_t stream) {
+    SegBox* T = (SegBox*)s.seg;
+    const uint32_t P = (uint32_t)s.seg_leaves, g = (n_tris + 255) / 256;
+    hipLaunchKernelGGL(k_seg_pass<true>, dim3(g), dim3(256), 0, stream, d_tris, T, P, n_tris);
+    uint32_t valid = g;                                          // entries of the level eight above that were written
+    for (uint32_t base = P >> 8; base > 1; base >>= 8) {         // (a pass that starts at level `base` ends at the root or 8 levels up)
+        hipLaunchKernelGGL(k_seg_pass<false>, dim3((valid + 255) / 256), dim3(256), 0, stream, (const TriPacket*)nullptr, T, base, valid);
+        valid = (valid + 255) / 256;
+    }
+}
+
 hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const InstanceRec* d_instances, int n_inst, uint32_t n_tris, Bvh4Node* d_nodes,
-                       TriPacket* d_tris, ShadePacket* d_shade, int32_t* root_out, uint32_t* wide_nodes_out, hipStream_t stream) {
+                       TriPacket* d_tris, ShadePacket* d_shade, int32_t* root_out, uint32_t* wide_nodes_out, uint32_t* stack_need_out, hipStream_t stream) {
     *root_out = 0;
     *wide_nodes_out = 0;
+    *stack_need_out = 0;
     if (n_tris == 0) return hipSuccess;
     hipError_t e = ensure(s, n_tris);
     if (e) return e;
@@ -510,24 +545,23 @@ hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const Instan
     hipLaunchKernelGGL(k_shade_packets, dim3(g), dim3(256), 0, stream, d_tris, n_tris, d_instances, d_shade);
     hipLaunchKernelGGL(k_hierarchy, dim3(g), dim3(256), 0, stream, s.keys_b, (int)n_tris, s.nodes2, s.node_parent, s.leaf_parent);
     const uint32_t n_nodes = n_tris - 1;
-    {
-        SegBox* T = (SegBox*)s.seg;
-        const uint32_t P = (uint32_t)s.seg_leaves;
-        hipLaunchKernelGGL(k_seg_pass<true>, dim3(g), dim3(256), 0, stream, d_tris, T, P, n_tris);
-        uint32_t valid = g;                                          // entries of the level eight above that were written
-        for (uint32_t base = P >> 8; base > 1; base >>= 8) {         // (a pass that starts at level `base` ends at the root or 8 levels up)
-            hipLaunchKernelGGL(k_seg_pass<false>, dim3((valid + 255) / 256), dim3(256), 0, stream, (const TriPacket*)nullptr, T, base, valid);
-            valid = (valid + 255) / 256;
-        }
-        hipLaunchKernelGGL(k_fit, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, T, P, n_nodes, s.nodes2);
-    }
+    seg_build(s, d_tris, n_tris, stream);
+    hipLaunchKernelGGL(k_fit, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, (const SegBox*)s.seg, (uint32_t)s.seg_leaves, n_nodes, s.nodes2);
     // greedy collapse, level by level: frontier = binary nodes that become wide nodes, with the wide index their parent gave them
     uint32_t* fr[2] = {s.kept, s.vals_a};
     uint32_t* wi[2] = {s.widx, s.vals_b};                            // (the sort's value buffers are free again by now)
-    hipLaunchKernelGGL(k_collapse_init, dim3(1), dim3(256), 0, stream, fr[0], wi[0], s.collapse_counters);
+    uint32_t* nd[2] = {(uint32_t*)s.leaf_parent, (uint32_t*)s.node_parent};   // (k_hierarchy's parent links are not read by anything)
+    hipLaunchKernelGGL(k_collapse_init, dim3(1), dim3(256), 0, stream, fr[0], wi[0], nd[0], s.collapse_counters);
     if (n_nodes <= kSmallCollapseNodes) {
-        hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(1024), 0, stream, s.nodes2, fr[0], wi[0], fr[1], wi[1], s.collapse_counters, d_nodes);
-        *wide_nodes_out = kWideNodesOnDevice;                       // no host round trip on this path: read s.collapse_counters[0] when asked
+        hipLaunchKernelGGL(k_collapse_small, dim3(1), dim3(1024), 0, stream, s.nodes2, fr[0], wi[0], fr[1], wi[1], s.collapse_counters, d_nodes, s.wide_ranges, nd[0], nd[1]);
+        // a full build is the rare event now (dynamic geometry is refitted): wait for the node count and the tree's depth, so
+        // that a tree too deep for the traversal stack is refused here instead of dropping pushes during a trace
+        uint32_t res[2] = {0, 0};
+        if ((e = hipMemcpyAsync(&res[0], s.collapse_counters, 4, hipMemcpyDeviceToHost, stream))) return e;
+        if ((e = hipMemcpyAsync(&res[1], s.collapse_counters + kCollapseNeedSlot, 4, hipMemcpyDeviceToHost, stream))) return e;
+        if ((e = hipStreamSynchronize(stream))) return e;
+        *wide_nodes_out = res[0];
+        *stack_need_out = res[1];
         return hipGetLastError();
     }
     // Levels are launched eight at a time with grids sized for the largest frontier each can have (four times the one before,
@@ -537,7 +571,7 @@ hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const Instan
         if (level >= (uint32_t)kCollapseMaxLevels) return hipErrorUnknown;   // far deeper than a 64-bit radix tree can be; guards a hang
         for (int j = 0; j < 8; j++, level++, cur ^= 1u) {
             hipLaunchKernelGGL(k_collapse_level, dim3((bound + 255) / 256), dim3(256), 0, stream, s.nodes2, fr[cur], wi[cur], level, fr[cur ^ 1u], wi[cur ^ 1u],
-                               s.collapse_counters, d_nodes);
+                               s.collapse_counters, d_nodes, s.wide_ranges, nd[cur], nd[cur ^ 1u]);
             bound = bound > n_nodes / kBvhWidth ? n_nodes : bound * kBvhWidth;
         }
         uint32_t next = 0;
@@ -545,9 +579,87 @@ hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const Instan
         if ((e = hipMemcpyAsync(wide_nodes_out, s.collapse_counters, 4, hipMemcpyDeviceToHost, stream))) return e;
         if ((e = hipStreamSynchronize(stream))) return e;
         if (next > n_nodes) return hipErrorUnknown;
-        if (next == 0) break;
+        if (next == 0) {
+            if ((e = hipMemcpy(stack_need_out, s.collapse_counters + kCollapseNeedSlot, 4, hipMemcpyDeviceToHost))) return e;
+            break;
+        }
         bound = next;
     }
+    return hipGetLastError();
+}
+
+// ---- refit (UpdateDynamicBlas, Source/RayTracingAccelerationStructure.cpp:110-158, as driven by Pathtracer::UpdateAllBlas,
+// Source/Pathtracer.cpp:168-183): the tree's topology, the triangles' sorted order and every untouched packet stay; the packets of the
+// instances whose vertices or transform changed are rewritten in place, the boxes follow.
+//
+// 1. one lane per sorted triangle: if its instance is marked, rebuild its 48-B intersection packet and its 128-B shading packet
+__global__ __launch_bounds__(256) void k_refit_packets(const InstanceRec* __restrict__ instances, const uint8_t* __restrict__ touched, uint32_t n_tris,
+                                                       TriPacket* __restrict__ tris, ShadePacket* __restrict__ shade) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tris) return;
+    const uint32_t inst = tris[i].inst;
+    if (!touched[inst]) return;
+    const InstanceRec& in = instances[inst];
+    const uint32_t prim = tris[i].prim;
+    ShadePacket p;
+    memset(&p, 0, sizeof(p));
+    vec3 w[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        uint32_t v = prim * 3 + k;
+        if (in.p_index) v = in.index_is16 ? (uint32_t)((const uint16_t*)in.p_index)[v] : ((const uint32_t*)in.p_index)[v];
+        ShadePacket::V& o = p.v[k];
+        const float* q = in.p_position + (size_t)v * 3;
+        o.pos[0] = q[0]; o.pos[1] = q[1]; o.pos[2] = q[2];
+        if (in.p_tangent_space) o.tangent_space = in.p_tangent_space[v];
+        if (in.p_texcoord[0]) { float2 t = in.p_texcoord[0][v]; o.uv0[0] = t.x; o.uv0[1] = t.y; }
+        if (in.p_texcoord[1]) { float2 t = in.p_texcoord[1][v]; o.uv1[0] = t.x; o.uv1[1] = t.y; }
+        if (in.p_color) { uint2 c = in.p_color[v]; o.color[0] = c.x; o.color[1] = c.y; }
+        w[k] = mul_point(in.gpu.transform, v3(q[0], q[1], q[2]));      // the expression k_setup evaluates: same bits as a rebuild
+    }
+    p.inst = inst;
+    TriPacket t;
+    t.v0[0] = w[0].x; t.v0[1] = w[0].y; t.v0[2] = w[0].z; t.inst = inst;
+    const vec3 e1 = w[1] - w[0], e2 = w[2] - w[0];
+    t.e1[0] = e1.x; t.e1[1] = e1.y; t.e1[2] = e1.z; t.prim = prim;
+    t.e2[0] = e2.x; t.e2[1] = e2.y; t.e2[2] = e2.z; t.flags = in.mask_flags;
+    tris[i] = t;
+    const float4* s4 = (const float4*)&p;
+    float4* d4 = (float4*)(shade + i);
+#pragma unroll
+    for (int q = 0; q < 8; q++) d4[q] = s4[q];
+}
+
+// 3. one lane per wide node: the children's boxes are range queries of the rebuilt segment tree over the ranges the collapse
+//    recorded; the node is requantised on its new grid.  Nodes whose ranges hold no changed triangle come out bit-identical.
+__global__ __launch_bounds__(256) void k_refit_wide(const SegBox* __restrict__ T, uint32_t P, const WideRanges* __restrict__ ranges,
+                                                    const uint32_t* __restrict__ wide_count, Bvh4Node* __restrict__ nodes) {
+    const uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= wide_count[0]) return;
+    const WideRanges wr = ranges[wi];
+    const uint32_t* words = (const uint32_t*)(nodes + wi);
+    int32_t ref[kBvhWidth];
+    float lo[kBvhWidth][3], hi[kBvhWidth][3];
+    int cnt = 0;
+    for (int k = 0; k < kBvhWidth; k++) {
+        if (wr.count[k] == 0) break;                         // children are packed from slot 0
+        ref[k] = (int32_t)words[4 + k];
+        seg_query(T, P, wr.first[k], wr.count[k], lo[k], hi[k]);
+        cnt++;
+    }
+    if (cnt) wide_write(nodes + wi, lo, hi, ref, cnt);
+}
+
+hipError_t accel_refit(AccelScratch& s, const InstanceRec* d_instances, const uint8_t* d_touched, uint32_t n_tris, uint32_t wide_nodes,
+                       Bvh4Node* d_nodes, TriPacket* d_tris, ShadePacket* d_shade, hipStream_t stream) {
+    if (n_tris == 0) return hipSuccess;
+    if (n_tris > s.capacity) return hipErrorInvalidValue;           // no build has sized the scratch: the caller must rebuild
+    const uint32_t g = (n_tris + 255) / 256;
+    hipLaunchKernelGGL(k_refit_packets, dim3(g), dim3(256), 0, stream, d_instances, d_touched, n_tris, d_tris, d_shade);
+    if (n_tris == 1) return hipGetLastError();                      // a single triangle has no node (root = ~0)
+    seg_build(s, d_tris, n_tris, stream);
+    hipLaunchKernelGGL(k_refit_wide, dim3((wide_nodes + 255) / 256), dim3(256), 0, stream, (const SegBox*)s.seg, (uint32_t)s.seg_leaves,
+                       (const WideRanges*)s.wide_ranges, (const uint32_t*)s.collapse_counters, d_nodes);
     return hipGetLastError();
 }
 

@@ -1254,6 +1254,28 @@ int gs_upload(gs_scene* s, pt_ctx* ctx) {
     return PT_OK;
 }
 
+// Gltf::Unload (Gltf.cpp:123-157), as LoadGltf calls it before loading the next file (Main.cpp:43-54): the per-frame tables that
+// point into this scene's resources are emptied first, then every stream, dynamic-mesh output and texture is released.
+int gs_unload(gs_scene* s, pt_ctx* ctx) {
+    if (!s || !ctx) return fail(PT_ERR_INVALID_ARGUMENT, "gs_unload: null argument");
+    if (!s->uploaded) return PT_OK;
+    GS_TRY(pt_scene_set_instances(ctx, nullptr, 0));
+    GS_TRY(pt_scene_set_materials(ctx, nullptr, 0));
+    auto drop = [&](int& h) -> int { if (h < 0) return PT_OK; int r = pt_buffer_destroy(ctx, h); h = -1; return r; };
+    for (auto& m : s->meshes)
+        for (auto& p : m.prims) {
+            GS_TRY(drop(p.h_index)); GS_TRY(drop(p.h_position)); GS_TRY(drop(p.h_tangent_space)); GS_TRY(drop(p.h_texcoord[0])); GS_TRY(drop(p.h_texcoord[1]));
+            GS_TRY(drop(p.h_color)); GS_TRY(drop(p.h_joint_weight));
+            for (auto& t : p.targets) { GS_TRY(drop(t.h_position)); GS_TRY(drop(t.h_tangent_space)); }
+        }
+    for (auto& d : s->dynamic)
+        for (auto& dm : d.meshes) { GS_TRY(drop(dm.h_position)); GS_TRY(drop(dm.h_tangent_space)); }
+    for (auto& t : s->textures)
+        if (t.loaded && t.handle >= 0) { GS_TRY(pt_texture_destroy(ctx, t.handle)); t.handle = -1; }
+    s->uploaded = false;                                       // samplers are plain records of the context and stay
+    return PT_OK;
+}
+
 int gs_frame(gs_scene* s, pt_ctx* ctx, int scene, int* light_count_out) {
     if (!s || !ctx) return fail(PT_ERR_INVALID_ARGUMENT, "gs_frame: null argument");
     if (!s->uploaded) return fail(PT_ERR_NOT_READY, "gs_frame: call gs_upload first");

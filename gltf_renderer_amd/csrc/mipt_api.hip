@@ -22,10 +22,27 @@
 
 using namespace pt;
 
+// Pinned upload slots for the per-frame tables (materials, lights, instances, bones, vertex updates).  The reference hands those
+// over in a transient upload heap that stays valid for the frame (Source/Renderer.cpp:490,496); here the caller's memory may be
+// reused as soon as the call returns, so the bytes are copied into a pinned slot and go to the device asynchronously.  The host
+// only ever waits when it comes round to a slot whose copy is still in flight -- not once per call.
+struct StagingRing {
+    static constexpr int kSlots = 8;
+    void* host[kSlots] = {};
+    size_t cap[kSlots] = {};
+    hipEvent_t done[kSlots] = {};
+    bool pending[kSlots] = {};
+    int next = 0;
+};
+
+enum AccelState { ACCEL_CLEAN = 0, ACCEL_REFIT = 1, ACCEL_REBUILD = 2 };
+
+
 struct pt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string error;
+    StagingRing staging;
 
     // ---- ResourceTable ("descriptor heap")
     std::vector<BufferRec> buffers;
@@ -36,6 +53,7 @@ struct pt_ctx {
 
     // ---- per-frame arrays (Renderer::GatherMaterials / GatherLights)
     RMat* d_rmats = nullptr; int n_materials = 0; size_t rmats_cap = 0;    // resolved on the host in pt_scene_set_materials
+    std::vector<RMat> rmats_host;                                          // what was uploaded (pt_texture_destroy checks it)
     pt_light* d_lights = nullptr; int n_lights = 0; size_t lights_cap = 0;
 
     // ---- instance table + acceleration structure
@@ -43,18 +61,31 @@ struct pt_ctx {
     InstanceRec* d_instances = nullptr; size_t instances_cap = 0;
     uint32_t n_tris = 0;
     Bvh4Node* d_nodes = nullptr; TriPacket* d_tris = nullptr; ShadePacket* d_shade = nullptr; size_t accel_cap = 0;
-    uint32_t wide_nodes = 0;
+    uint32_t wide_nodes = 0, stack_need = 0;
     int32_t root = 0;
     AccelScratch scratch;
-    bool accel_dirty = true;
+    // What the next pt_build_accel / pt_trace has to do: nothing, a refit of the instances marked in `touched` (vertices or
+    // transform changed: UpdateDynamicBlas + the per-frame TLAS rebuild upstream), or a full build (topology changed).
+    int accel_state = ACCEL_REBUILD;
+    bool accel_built = false;                 // a full build of the current instance table exists (a refit needs one)
+    bool instances_dirty = true;              // the device copy of the instance table is stale
+    std::vector<uint8_t> touched;             // per instance
+    uint8_t* d_touched = nullptr; size_t touched_cap = 0;
+    uint32_t accel_refits = 0, accel_builds = 0;
+    std::vector<int> free_buffers, free_textures, free_envs;      // destroyed handles, reused by the next create
 
     std::vector<EnvDevice*> envs;
     float* d_sheen = nullptr;
     float* d_srgb = nullptr;
     float2* d_tangent_lut = nullptr;
     Counters* d_counters = nullptr;
-    void* d_bones = nullptr; size_t bones_cap = 0;
+    void* d_bones = nullptr; size_t bones_cap = 0, bones_used = 0;   // bone arena: one slice per pt_skin_run, wraps behind a fence
+    hipEvent_t bones_fence = nullptr; bool bones_fence_pending = false;
     void* d_workspace = nullptr; size_t workspace_cap = 0;     // wavefront ray / hit / path-state arrays
+    void* d_tonemap = nullptr; size_t tonemap_cap = 0;         // pt_tonemap's device scratch (float RGB + RGBA8), reused
+    pt::ExchangeState* exchange = nullptr;                         // pt_exchange_* (exchange.hip)
+    bool stage_timing = false;                                 // pt_enable_stage_timing
+    StageTimers timers;
     int kernel_mode = PT_MODE_WAVEFRONT;
     int stage_blocks = 0;         // workgroups per stage launch; 0 = by the size of the launch (stage_blocks_for)
     hipEvent_t ev_trace[2] = {nullptr, nullptr}, ev_accel[2] = {nullptr, nullptr}, ev_skin[2] = {nullptr, nullptr};
@@ -76,24 +107,55 @@ struct pt_ctx {
         hipError_t _e = (call);                                                                              \
         if (_e != hipSuccess) return ctx->fail(PT_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(_e)); \
     } while (0)
+// Every entry point that touches the device makes the context's device current first: two contexts on two GPUs in one process
+// (one per rank thread, or a host that drives several GPUs itself) must not launch or allocate on each other's device.
+#define ENTER(ctx)                                                                                           \
+    do {                                                                                                     \
+        hipError_t _e = hipSetDevice((ctx)->device);                                                         \
+        if (_e != hipSuccess) return (ctx)->fail(PT_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(_e)); \
+    } while (0)
 
 namespace {
 
+// Host -> device through a pinned slot of the ring, asynchronous on the context's stream.
+hipError_t staged_upload(pt_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return hipSuccess;
+    StagingRing& r = ctx->staging;
+    const int k = r.next;
+    r.next = (r.next + 1) % StagingRing::kSlots;
+    hipError_t e;
+    if (r.pending[k]) { if ((e = hipEventSynchronize(r.done[k]))) return e; r.pending[k] = false; }
+    if (bytes > r.cap[k]) {
+        if (r.host[k]) hipHostFree(r.host[k]);
+        r.host[k] = nullptr; r.cap[k] = 0;
+        const size_t nc = bytes + bytes / 2 + 4096;
+        if ((e = hipHostMalloc(&r.host[k], nc, hipHostMallocDefault))) return e;
+        r.cap[k] = nc;
+    }
+    if (!r.done[k] && (e = hipEventCreateWithFlags(&r.done[k], hipEventDisableTiming))) return e;
+    memcpy(r.host[k], src, bytes);
+    if ((e = hipMemcpyAsync(dst, r.host[k], bytes, hipMemcpyHostToDevice, ctx->stream))) return e;
+    if ((e = hipEventRecord(r.done[k], ctx->stream))) return e;
+    r.pending[k] = true;
+    return hipSuccess;
+}
+
 template <typename T>
-hipError_t upload_table(T*& d, size_t& cap, const std::vector<T>& h, hipStream_t s) {
+hipError_t upload_table(pt_ctx* ctx, T*& d, size_t& cap, const std::vector<T>& h) {
     size_t n = h.size() ? h.size() : 1;
     if (n > cap) {
+        // kernels already enqueued may still read the old table
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e) return e;
         hipFree(d);
-        d = nullptr;
+        d = nullptr; cap = 0;
         size_t nc = n + n / 2 + 8;
-        hipError_t e = hipMalloc((void**)&d, nc * sizeof(T));
+        e = hipMalloc((void**)&d, nc * sizeof(T));
         if (e) return e;
         cap = nc;
     }
     if (h.empty()) return hipSuccess;
-    hipError_t e = hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
-    if (e) return e;
-    return hipStreamSynchronize(s);      // h may be a temporary of the caller's frame (transient heap semantics)
+    return staged_upload(ctx, d, h.data(), h.size() * sizeof(T));
 }
 
 // glm closed forms.  Inverses in fp64, rounded once.
@@ -155,6 +217,24 @@ size_t format_stride(int f) {
 // 1632 / 1685 / 1551, 2.07 M slots 2500 / 2697 / 3149.
 int stage_blocks_for(size_t slots) { return slots >= 1200000 ? 1536 : (slots >= 400000 ? 768 : 512); }
 
+// A vertex stream was rewritten (pt_skin_run, pt_buffer_update): the instances that read it need their packets rebuilt (refit);
+// a rewritten index stream changes which vertices form a triangle, which the refit also handles (it re-reads the indices), but
+// the Morton order was made for the old triangles -- still correct, only slower -- so that stays a refit too.
+void mark_buffer_users(pt_ctx* ctx, int handle) {
+    if (handle < 0) return;
+    if (ctx->touched.size() != ctx->instances.size()) ctx->touched.assign(ctx->instances.size(), 0);
+    const void* ptr = ctx->buffers[handle].ptr;
+    bool any = false;
+    for (size_t i = 0; i < ctx->instances.size(); i++) {
+        const InstanceRec& r = ctx->instances[i];
+        if (r.p_index == ptr || r.p_position == ptr || r.p_tangent_space == ptr || r.p_texcoord[0] == ptr || r.p_texcoord[1] == ptr || r.p_color == ptr) {
+            ctx->touched[i] = 1;
+            any = true;
+        }
+    }
+    if (any && ctx->accel_state == ACCEL_CLEAN) ctx->accel_state = ACCEL_REFIT;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -162,26 +242,58 @@ int stage_blocks_for(size_t slots) { return slots >= 1200000 ? 1536 : (slots >= 
 namespace pt {
 class Pathtracer {
 public:
-    // Pathtracer::BuildAllBlas + UpdateAllBlas + BuildTlas (Source/Pathtracer.cpp:138-257)
+    // Pathtracer::BuildAllBlas + UpdateAllBlas + BuildTlas (Source/Pathtracer.cpp:138-257).  Upstream builds a BLAS once per
+    // primitive, refits the dynamic ones every frame (UpdateDynamicBlas, RayTracingAccelerationStructure.cpp:110-158) and rebuilds a
+    // small TLAS every frame.  Here: ONE full build of the flattened soup when the set of triangles changes, and a refit -- packets
+    // of the touched instances rewritten in place, every box re-derived -- when only vertices or transforms moved.
     static int BuildAccel(pt_ctx* ctx) {
-        if (ctx->buffers_dirty) { HIPOK(upload_table(ctx->d_buffers, ctx->d_buffers_cap, ctx->buffers, ctx->stream)); ctx->buffers_dirty = false; }
-        HIPOK(upload_table(ctx->d_instances, ctx->instances_cap, ctx->instances, ctx->stream));
-        size_t need = ctx->n_tris ? ctx->n_tris : 1;
-        if (need > ctx->accel_cap) {
-            hipFree(ctx->d_nodes); hipFree(ctx->d_tris); hipFree(ctx->d_shade);
-            ctx->d_nodes = nullptr; ctx->d_tris = nullptr; ctx->d_shade = nullptr;
-            size_t cap = need + need / 8 + 64;
-            HIPOK(hipMalloc((void**)&ctx->d_nodes, cap * sizeof(Bvh4Node)));
-            HIPOK(hipMalloc((void**)&ctx->d_tris, cap * sizeof(TriPacket)));
-            HIPOK(hipMalloc((void**)&ctx->d_shade, cap * sizeof(ShadePacket)));
-            ctx->accel_cap = cap;
+        if (ctx->buffers_dirty) { HIPOK(upload_table(ctx, ctx->d_buffers, ctx->d_buffers_cap, ctx->buffers)); ctx->buffers_dirty = false; }
+        if (ctx->instances_dirty) { HIPOK(upload_table(ctx, ctx->d_instances, ctx->instances_cap, ctx->instances)); ctx->instances_dirty = false; }
+        if (ctx->accel_state == ACCEL_CLEAN && ctx->accel_built) return PT_OK;
+        const bool refit = ctx->accel_built && ctx->accel_state == ACCEL_REFIT;
+        if (!refit) {
+            size_t need = ctx->n_tris ? ctx->n_tris : 1;
+            if (need > ctx->accel_cap) {
+                HIPOK(hipStreamSynchronize(ctx->stream));
+                hipFree(ctx->d_nodes); hipFree(ctx->d_tris); hipFree(ctx->d_shade);
+                ctx->d_nodes = nullptr; ctx->d_tris = nullptr; ctx->d_shade = nullptr; ctx->accel_cap = 0;
+                size_t cap = need + need / 8 + 64;
+                HIPOK(hipMalloc((void**)&ctx->d_nodes, cap * sizeof(Bvh4Node)));
+                HIPOK(hipMalloc((void**)&ctx->d_tris, cap * sizeof(TriPacket)));
+                HIPOK(hipMalloc((void**)&ctx->d_shade, cap * sizeof(ShadePacket)));
+                ctx->accel_cap = cap;
+            }
         }
         HIPOK(hipEventRecord(ctx->ev_accel[0], ctx->stream));
-        HIPOK(accel_build(ctx->scratch, ctx->d_buffers, ctx->d_instances, (int)ctx->instances.size(), ctx->n_tris, ctx->d_nodes, ctx->d_tris, ctx->d_shade,
-                          &ctx->root, &ctx->wide_nodes, ctx->stream));
+        if (refit) {
+            const size_t n = ctx->instances.size();
+            if (n > ctx->touched_cap) {
+                HIPOK(hipStreamSynchronize(ctx->stream));
+                hipFree(ctx->d_touched); ctx->d_touched = nullptr; ctx->touched_cap = 0;
+                HIPOK(hipMalloc((void**)&ctx->d_touched, n + 64));
+                ctx->touched_cap = n + 64;
+            }
+            HIPOK(staged_upload(ctx, ctx->d_touched, ctx->touched.data(), n));
+            HIPOK(accel_refit(ctx->scratch, ctx->d_instances, ctx->d_touched, ctx->n_tris, ctx->wide_nodes, ctx->d_nodes, ctx->d_tris, ctx->d_shade, ctx->stream));
+            ctx->accel_refits++;
+        } else {
+            HIPOK(accel_build(ctx->scratch, ctx->d_buffers, ctx->d_instances, (int)ctx->instances.size(), ctx->n_tris, ctx->d_nodes, ctx->d_tris, ctx->d_shade,
+                              &ctx->root, &ctx->wide_nodes, &ctx->stack_need, ctx->stream));
+            ctx->accel_builds++;
+        }
         HIPOK(hipEventRecord(ctx->ev_accel[1], ctx->stream));
         ctx->have_accel = true;
-        ctx->accel_dirty = false;
+        ctx->accel_state = ACCEL_CLEAN;
+        ctx->accel_built = true;
+        std::fill(ctx->touched.begin(), ctx->touched.end(), (uint8_t)0);
+        // The build reports the most stack entries any ray can hold in this tree (a node pushes its other children).  A tree that
+        // needs more than rays have (long chains of equal Morton codes: thousands of coincident centroids) would silently drop
+        // pushes, i.e. geometry: refuse it here, loudly.  A refit keeps the topology, so the figure of the build stands.
+        if (!refit && (int)ctx->stack_need > traversal_stack_capacity()) {
+            ctx->accel_built = false; ctx->accel_state = ACCEL_REBUILD;
+            return ctx->fail(PT_ERR_CAPACITY, "acceleration structure needs a traversal stack of " + std::to_string(ctx->stack_need) + " entries; rays have " +
+                                              std::to_string(traversal_stack_capacity()) + " (too many coincident triangle centroids)");
+        }
         return PT_OK;
     }
 
@@ -195,9 +307,10 @@ public:
         if (reset) ctx->accumulated_frames = 0;
         if (ctx->accumulated_frames < settings->max_accumulated_frames) {               // :273
             if (ep->light_count > ctx->n_lights) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "light_count exceeds uploaded lights");
-            if (ep->environment_map >= (int)ctx->envs.size()) return ctx->fail(PT_ERR_BAD_HANDLE, "bad environment map handle");
+            if (ep->environment_map >= 0 && (ep->environment_map >= (int)ctx->envs.size() || !ctx->envs[ep->environment_map]))
+                return ctx->fail(PT_ERR_BAD_HANDLE, "bad environment map handle");
             if (!ep->output) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "output is null");
-            if (ctx->accel_dirty) { int r = BuildAccel(ctx); if (r) return r; }
+            if (ctx->accel_state != ACCEL_CLEAN || !ctx->accel_built || ctx->instances_dirty) { int r = BuildAccel(ctx); if (r) return r; }
 
             SceneRec sc;
             memset(&sc, 0, sizeof(sc));
@@ -275,7 +388,8 @@ public:
                     HIPOK(hipMalloc(&ctx->d_workspace, need));
                     ctx->workspace_cap = need;
                 }
-                HIPOK(launch_wavefront(sc, fc, (float4*)ep->output, ctx->d_counters, ctx->counters_enabled, ctx->d_workspace, stage_blocks, ctx->stream));
+                HIPOK(launch_wavefront(sc, fc, (float4*)ep->output, ctx->d_counters, ctx->counters_enabled, ctx->d_workspace, stage_blocks,
+                                       ctx->stage_timing ? &ctx->timers : nullptr, ctx->stream));
             }
             HIPOK(hipGetLastError());
             HIPOK(hipEventRecord(ctx->ev_trace[1], ctx->stream));
@@ -340,26 +454,43 @@ public:
         }
         if (a.input_mesh_flags & PT_MESH_FLAG_JOINT_WEIGHT) {
             size_t bytes = (size_t)bone_count * sizeof(pt_bone);
-            if (bytes > ctx->bones_cap) {
-                hipFree(ctx->d_bones); ctx->d_bones = nullptr; ctx->bones_cap = 0;
-                HIPOK(hipMalloc(&ctx->d_bones, bytes * 2));
-                ctx->bones_cap = bytes * 2;
+            // Each call gets its own slice of the bone arena: a frame skins several primitives back to back on one stream, and the
+            // kernel of the previous call may not have read its bones yet (they live in the caller's transient heap, Renderer.cpp:411).
+            if (ctx->bones_used + bytes > ctx->bones_cap) {
+                if (bytes > ctx->bones_cap) {
+                    HIPOK(hipStreamSynchronize(ctx->stream));
+                    hipFree(ctx->d_bones); ctx->d_bones = nullptr; ctx->bones_cap = 0;
+                    const size_t nc = bytes * 8 + 4096;
+                    HIPOK(hipMalloc(&ctx->d_bones, nc));
+                    ctx->bones_cap = nc;
+                } else if (ctx->bones_fence_pending) HIPOK(hipEventSynchronize(ctx->bones_fence));      // wrap: the arena's earlier readers must be done
+                ctx->bones_used = 0;
             }
-            HIPOK(hipMemcpyAsync(ctx->d_bones, bones, bytes, hipMemcpyHostToDevice, ctx->stream));
-            HIPOK(hipStreamSynchronize(ctx->stream));        // bones live in the caller's transient heap (Renderer.cpp:411)
-            a.bones = (const pt_bone*)ctx->d_bones;
+            void* dst = (char*)ctx->d_bones + ctx->bones_used;
+            ctx->bones_used += (bytes + 255) & ~(size_t)255;
+            HIPOK(staged_upload(ctx, dst, bones, bytes));
+            a.bones = (const pt_bone*)dst;
             a.bone_count = bone_count;
         }
         HIPOK(hipEventRecord(ctx->ev_skin[0], ctx->stream));
         launch_skin(a, p->use_mfma != 0, ctx->stream);
         HIPOK(hipGetLastError());
         HIPOK(hipEventRecord(ctx->ev_skin[1], ctx->stream));
+        if (a.bones) { HIPOK(hipEventRecord(ctx->bones_fence, ctx->stream)); ctx->bones_fence_pending = true; }
         ctx->have_skin = true;
-        ctx->accel_dirty = true;                              // UpdateAllBlas runs every frame for dynamic meshes (Pathtracer.cpp:168-183)
+        // UpdateAllBlas refits every dynamic primitive every frame (Pathtracer.cpp:168-183): the instances that read the streams
+        // just written are refitted by the next pt_build_accel / pt_trace
+        if (a.out_position) mark_buffer_users(ctx, p->output_position);
+        if (a.out_tangent_space) mark_buffer_users(ctx, p->output_tangent_space);
         return PT_OK;
     }
 };
 }  // namespace pt
+
+static int exchange_frame_checked(pt_ctx* ctx, const void* local, void* frame, uint32_t w, uint32_t h, int mode, int dst, std::string& err) {
+    // (rank / world live in the exchange state; the root needs somewhere to put the frame)
+    return exchange_frame(ctx->exchange, local, frame ? frame : const_cast<void*>(local), w, h, mode, dst, ctx->stream, err);
+}
 
 // =================================================================================================
 // C-ABI
@@ -391,6 +522,7 @@ int pt_create(int device, void* hip_stream, const float* sheen_e_16x16, pt_ctx**
               build_tangent_lut(ctx->d_tangent_lut, ctx->stream) == hipSuccess;
     for (int i = 0; i < 2 && ok; i++)
         ok = hipEventCreate(&ctx->ev_trace[i]) == hipSuccess && hipEventCreate(&ctx->ev_accel[i]) == hipSuccess && hipEventCreate(&ctx->ev_skin[i]) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&ctx->bones_fence, hipEventDisableTiming) == hipSuccess;
     if (!ok) { pt_destroy(ctx); return PT_ERR_DEVICE; }
     ctx->samplers.push_back({PT_ADDRESS_WRAP, PT_ADDRESS_WRAP, PT_FILTER_LINEAR, PT_FILTER_LINEAR});   // sampler 0 (GpuResources.cpp:47-59)
     *out = ctx;
@@ -403,12 +535,21 @@ void pt_destroy(pt_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     for (auto& b : ctx->buffers) hipFree((void*)b.ptr);
     for (auto& t : ctx->textures) hipFree((void*)t.texels);
-    for (auto* e : ctx->envs) { env_free(*e); delete e; }
+    for (auto* e : ctx->envs) if (e) { env_free(*e); delete e; }
     hipFree(ctx->d_buffers); hipFree(ctx->d_white); hipFree(ctx->d_rmats); hipFree(ctx->d_lights);
     hipFree(ctx->d_instances); hipFree(ctx->d_nodes); hipFree(ctx->d_tris); hipFree(ctx->d_shade); hipFree(ctx->d_sheen); hipFree(ctx->d_srgb); hipFree(ctx->d_tangent_lut); hipFree(ctx->d_counters);
     accel_scratch_free(ctx->scratch);
     hipFree(ctx->d_bones);
     hipFree(ctx->d_workspace);
+    hipFree(ctx->d_tonemap);
+    hipFree(ctx->d_touched);
+    exchange_free(ctx->exchange);
+    for (int k = 0; k < StagingRing::kSlots; k++) {
+        if (ctx->staging.host[k]) hipHostFree(ctx->staging.host[k]);
+        if (ctx->staging.done[k]) hipEventDestroy(ctx->staging.done[k]);
+    }
+    for (hipEvent_t e : ctx->timers.ev) hipEventDestroy(e);
+    if (ctx->bones_fence) hipEventDestroy(ctx->bones_fence);
     for (int i = 0; i < 2; i++) {
         if (ctx->ev_trace[i]) hipEventDestroy(ctx->ev_trace[i]);
         if (ctx->ev_accel[i]) hipEventDestroy(ctx->ev_accel[i]);
@@ -422,41 +563,84 @@ const char* pt_last_error(const pt_ctx* ctx) { return ctx ? ctx->error.c_str() :
 int pt_buffer_create(pt_ctx* ctx, const void* host, size_t bytes, int format, int* handle_out) {
     if (!ctx || !handle_out) return PT_ERR_INVALID_ARGUMENT;
     if (format_stride(format) == 0 || bytes == 0 || bytes > 0xffffffffull) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "pt_buffer_create: bad format or size");
+    ENTER(ctx);
     void* d = nullptr;
     HIPOK(hipMalloc(&d, bytes + 16));
-    if (host) HIPOK(hipMemcpy(d, host, bytes, hipMemcpyHostToDevice));
-    else HIPOK(hipMemset(d, 0, bytes));
-    ctx->buffers.push_back({d, (uint32_t)format, (uint32_t)bytes});
+    hipError_t e = host ? hipMemcpy(d, host, bytes, hipMemcpyHostToDevice) : hipMemset(d, 0, bytes);
+    if (e) { hipFree(d); return ctx->fail(PT_ERR_DEVICE, std::string("pt_buffer_create: ") + hipGetErrorString(e)); }
+    const BufferRec rec = {d, (uint32_t)format, (uint32_t)bytes};
+    if (!ctx->free_buffers.empty()) { *handle_out = ctx->free_buffers.back(); ctx->free_buffers.pop_back(); ctx->buffers[*handle_out] = rec; }
+    else { ctx->buffers.push_back(rec); *handle_out = (int)ctx->buffers.size() - 1; }
     ctx->buffers_dirty = true;
-    *handle_out = (int)ctx->buffers.size() - 1;
     return PT_OK;
 }
 
+static bool live_buffer(const pt_ctx* ctx, int h) { return h >= 0 && h < (int)ctx->buffers.size() && ctx->buffers[h].ptr != nullptr; }
+
 int pt_buffer_update(pt_ctx* ctx, int handle, const void* host, size_t bytes) {
     if (!ctx || !host) return PT_ERR_INVALID_ARGUMENT;
-    if (handle < 0 || handle >= (int)ctx->buffers.size() || bytes > ctx->buffers[handle].bytes) return ctx->fail(PT_ERR_BAD_HANDLE, "pt_buffer_update");
-    HIPOK(hipMemcpyAsync((void*)ctx->buffers[handle].ptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIPOK(hipStreamSynchronize(ctx->stream));
-    ctx->accel_dirty = true;
+    if (!live_buffer(ctx, handle) || bytes > ctx->buffers[handle].bytes) return ctx->fail(PT_ERR_BAD_HANDLE, "pt_buffer_update");
+    ENTER(ctx);
+    HIPOK(staged_upload(ctx, (void*)ctx->buffers[handle].ptr, host, bytes));
+    mark_buffer_users(ctx, handle);
     return PT_OK;
 }
 
 int pt_buffer_read(pt_ctx* ctx, int handle, void* host, size_t bytes) {
     if (!ctx || !host) return PT_ERR_INVALID_ARGUMENT;
-    if (handle < 0 || handle >= (int)ctx->buffers.size() || bytes > ctx->buffers[handle].bytes) return ctx->fail(PT_ERR_BAD_HANDLE, "pt_buffer_read");
+    if (!live_buffer(ctx, handle) || bytes > ctx->buffers[handle].bytes) return ctx->fail(PT_ERR_BAD_HANDLE, "pt_buffer_read");
+    ENTER(ctx);
     HIPOK(hipStreamSynchronize(ctx->stream));
     HIPOK(hipMemcpy(host, ctx->buffers[handle].ptr, bytes, hipMemcpyDeviceToHost));
     return PT_OK;
 }
 
+// Gltf::Unload (Source/Gltf.cpp:123-157) destroys every mesh, texture and dynamic mesh of the old scene before the next is loaded
+// (Source/Main.cpp:43-54).  A resource the current instance table / material table still points at cannot go: the host replaces
+// those tables first (pt_scene_set_instances / pt_scene_set_materials with the new scene, or with count 0), as upstream's
+// per-frame tables are rebuilt from the new scene.
+int pt_buffer_destroy(pt_ctx* ctx, int handle) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    if (!live_buffer(ctx, handle)) return ctx->fail(PT_ERR_BAD_HANDLE, "pt_buffer_destroy");
+    const void* ptr = ctx->buffers[handle].ptr;
+    for (const InstanceRec& r : ctx->instances)
+        if (r.p_index == ptr || r.p_position == ptr || r.p_tangent_space == ptr || r.p_texcoord[0] == ptr || r.p_texcoord[1] == ptr || r.p_color == ptr)
+            return ctx->fail(PT_ERR_NOT_READY, "pt_buffer_destroy: the buffer is used by the current instance table (replace it with pt_scene_set_instances first)");
+    ENTER(ctx);
+    HIPOK(hipStreamSynchronize(ctx->stream));                // enqueued kernels (skinning, an earlier trace) may still read or write it
+    hipFree((void*)ptr);
+    ctx->buffers[handle] = BufferRec{nullptr, 0u, 0u};
+    ctx->free_buffers.push_back(handle);
+    ctx->buffers_dirty = true;
+    return PT_OK;
+}
+
 int pt_texture_create(pt_ctx* ctx, const uint8_t* rgba8, int width, int height, int srgb, int* handle_out) {
     if (!ctx || !rgba8 || !handle_out || width <= 0 || height <= 0) return PT_ERR_INVALID_ARGUMENT;
+    ENTER(ctx);
     void* d = nullptr;
     size_t bytes = (size_t)width * height * 4;
     HIPOK(hipMalloc(&d, bytes));
-    HIPOK(hipMemcpy(d, rgba8, bytes, hipMemcpyHostToDevice));
-    ctx->textures.push_back({(const uint32_t*)d, width, height, srgb ? 1u : 0u, 0u});
-    *handle_out = (int)ctx->textures.size() - 1;
+    hipError_t e = hipMemcpy(d, rgba8, bytes, hipMemcpyHostToDevice);
+    if (e) { hipFree(d); return ctx->fail(PT_ERR_DEVICE, std::string("pt_texture_create: ") + hipGetErrorString(e)); }
+    const TextureRec rec = {(const uint32_t*)d, width, height, srgb ? 1u : 0u, 0u};
+    if (!ctx->free_textures.empty()) { *handle_out = ctx->free_textures.back(); ctx->free_textures.pop_back(); ctx->textures[*handle_out] = rec; }
+    else { ctx->textures.push_back(rec); *handle_out = (int)ctx->textures.size() - 1; }
+    return PT_OK;
+}
+
+int pt_texture_destroy(pt_ctx* ctx, int handle) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    if (handle < 0 || handle >= (int)ctx->textures.size() || !ctx->textures[handle].texels) return ctx->fail(PT_ERR_BAD_HANDLE, "pt_texture_destroy");
+    for (const RMat& m : ctx->rmats_host)
+        for (int k = 0; k < SLOT_COUNT; k++)
+            if (m.tex[k].texels == ctx->textures[handle].texels)
+                return ctx->fail(PT_ERR_NOT_READY, "pt_texture_destroy: the texture is used by the current material table (replace it with pt_scene_set_materials first)");
+    ENTER(ctx);
+    HIPOK(hipStreamSynchronize(ctx->stream));
+    hipFree((void*)ctx->textures[handle].texels);
+    ctx->textures[handle] = TextureRec{nullptr, 0, 0, 0u, 0u};
+    ctx->free_textures.push_back(handle);
     return PT_OK;
 }
 
@@ -470,12 +654,20 @@ int pt_sampler_create(pt_ctx* ctx, const pt_sampler_desc* d, int* handle_out) {
 
 int pt_scene_set_materials(pt_ctx* ctx, const pt_material* m, int count) {
     if (!ctx || (count > 0 && !m) || count < 0) return PT_ERR_INVALID_ARGUMENT;
+    // the instance table's material ids index this table: a shorter table must not leave one dangling (device reads of rmats[] and
+    // of the LDS material cache are not bounds-checked)
+    for (const InstanceRec& r : ctx->instances)
+        if (r.gpu.material_id >= count)
+            return ctx->fail(PT_ERR_BAD_HANDLE, "pt_scene_set_materials: the current instance table uses material " + std::to_string(r.gpu.material_id) +
+                                                ", the new table has " + std::to_string(count) + " (replace the instances first)");
+    ENTER(ctx);
     for (int i = 0; i < count; i++) {
         const pt_texture_sample* slots[15] = {&m[i].normal, &m[i].albedo, &m[i].metallic_roughness, &m[i].occlusion, &m[i].emissive, &m[i].specular,
                                               &m[i].specular_color, &m[i].clearcoat, &m[i].clearcoat_roughness, &m[i].clearcoat_normal, &m[i].anisotropy,
                                               &m[i].sheen_color, &m[i].sheen_roughness, &m[i].transmission, &m[i].thickness};
         for (auto* s : slots) {
-            if (s->descriptor < -1 || s->descriptor >= (int)ctx->textures.size()) return ctx->fail(PT_ERR_BAD_HANDLE, "material texture descriptor out of range");
+            if (s->descriptor < -1 || s->descriptor >= (int)ctx->textures.size() || (s->descriptor >= 0 && !ctx->textures[s->descriptor].texels))
+                return ctx->fail(PT_ERR_BAD_HANDLE, "material texture descriptor out of range or destroyed");
             if (s->sampler < 0 || s->sampler >= (int)ctx->samplers.size()) return ctx->fail(PT_ERR_BAD_HANDLE, "material sampler out of range");
         }
     }
@@ -518,15 +710,17 @@ int pt_scene_set_materials(pt_ctx* ctx, const pt_material* m, int count) {
             r.bound_mask |= 1u << k;
         }
     }
-    HIPOK(upload_table(ctx->d_rmats, ctx->rmats_cap, rm, ctx->stream));
+    HIPOK(upload_table(ctx, ctx->d_rmats, ctx->rmats_cap, rm));
+    ctx->rmats_host.swap(rm);
     ctx->n_materials = count;
     return PT_OK;
 }
 
 int pt_scene_set_lights(pt_ctx* ctx, const pt_light* l, int count) {
     if (!ctx || (count > 0 && !l) || count < 0) return PT_ERR_INVALID_ARGUMENT;
+    ENTER(ctx);
     std::vector<pt_light> h(l, l + count);
-    HIPOK(upload_table(ctx->d_lights, ctx->lights_cap, h, ctx->stream));
+    HIPOK(upload_table(ctx, ctx->d_lights, ctx->lights_cap, h));
     ctx->n_lights = count;
     return PT_OK;
 }
@@ -538,7 +732,7 @@ int pt_scene_set_instances(pt_ctx* ctx, const pt_instance_desc* in, int count) {
     uint64_t tris = 0;
     auto check = [&](int h, int fmt_a, int fmt_b, size_t count_needed) -> bool {
         if (h == -1) return true;
-        if (h < 0 || h >= (int)ctx->buffers.size()) return false;
+        if (!live_buffer(ctx, h)) return false;
         const BufferRec& b = ctx->buffers[h];
         if ((int)b.format != fmt_a && (int)b.format != fmt_b) return false;
         return b.bytes >= count_needed * format_stride(b.format);
@@ -578,14 +772,43 @@ int pt_scene_set_instances(pt_ctx* ctx, const pt_instance_desc* in, int count) {
         if (tris > 0x0fffffffull) return ctx->fail(PT_ERR_CAPACITY, "too many triangles (leaf references hold 28 bits of triangle index)");
         recs.push_back(r);
     }
+    // What the new table asks of the acceleration structure (the reference rebuilds its TLAS every frame, Pathtracer.cpp:282, which
+    // makes a moved instance free; here instances are flattened into one tree):
+    //   identical table            -> nothing (gs_frame re-sends the table every frame, also for a static scene);
+    //   same triangles, rows differ -> refit of the rows that differ (transform, flags, streams re-pointed at same-sized buffers);
+    //   anything else              -> full build.
+    const std::vector<InstanceRec>& old = ctx->instances;
+    bool same_shape = ctx->accel_built && old.size() == recs.size() && ctx->n_tris == (uint32_t)tris;
+    for (size_t i = 0; same_shape && i < recs.size(); i++)
+        same_shape = old[i].tri_count == recs[i].tri_count && old[i].tri_offset == recs[i].tri_offset;
+    if (same_shape) {
+        if (ctx->touched.size() != recs.size()) ctx->touched.assign(recs.size(), 0);
+        bool any = false;
+        for (size_t i = 0; i < recs.size(); i++) {
+            if (memcmp(&old[i], &recs[i], sizeof(InstanceRec)) == 0) continue;
+            any = true;
+            // a row that differs only in its material id leaves every packet as it is (the packets name the instance, not the material)
+            InstanceRec a = old[i], b = recs[i];
+            a.gpu.material_id = b.gpu.material_id = 0;
+            if (memcmp(&a, &b, sizeof(InstanceRec)) != 0) ctx->touched[i] = 1;
+        }
+        if (!any) return PT_OK;
+        bool refit = false;
+        for (uint8_t t : ctx->touched) refit = refit || t != 0;
+        if (refit && ctx->accel_state == ACCEL_CLEAN) ctx->accel_state = ACCEL_REFIT;
+    } else {
+        ctx->accel_state = ACCEL_REBUILD;
+        ctx->touched.assign(recs.size(), 0);
+    }
     ctx->instances.swap(recs);
+    ctx->instances_dirty = true;
     ctx->n_tris = (uint32_t)tris;
-    ctx->accel_dirty = true;
     return PT_OK;
 }
 
 int pt_env_create(pt_ctx* ctx, const float* rgb, int width, int height, int* env_out) {
     if (!ctx || !rgb || !env_out || width <= 0 || height <= 0) return PT_ERR_INVALID_ARGUMENT;
+    ENTER(ctx);
     float* d = nullptr;
     size_t bytes = (size_t)width * height * 12;
     HIPOK(hipMalloc((void**)&d, bytes));
@@ -595,14 +818,31 @@ int pt_env_create(pt_ctx* ctx, const float* rgb, int width, int height, int* env
     if (!e) e = hipStreamSynchronize(ctx->stream);
     hipFree(d);
     if (e) { env_free(*env); delete env; return ctx->fail(PT_ERR_DEVICE, std::string("pt_env_create: ") + hipGetErrorString(e)); }
-    ctx->envs.push_back(env);
-    *env_out = (int)ctx->envs.size() - 1;
+    if (!ctx->free_envs.empty()) { *env_out = ctx->free_envs.back(); ctx->free_envs.pop_back(); ctx->envs[*env_out] = env; }
+    else { ctx->envs.push_back(env); *env_out = (int)ctx->envs.size() - 1; }
+    return PT_OK;
+}
+
+static bool live_env(const pt_ctx* ctx, int env) { return env >= 0 && env < (int)ctx->envs.size() && ctx->envs[env] != nullptr; }
+
+// EnvironmentMap::Destroy: the maps of one environment (the reference replaces its single environment map in place when a new
+// image is loaded, Source/EnvironmentMap.cpp:84-130).
+int pt_env_destroy(pt_ctx* ctx, int env) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    if (!live_env(ctx, env)) return ctx->fail(PT_ERR_BAD_HANDLE, "pt_env_destroy");
+    ENTER(ctx);
+    HIPOK(hipStreamSynchronize(ctx->stream));
+    env_free(*ctx->envs[env]);
+    delete ctx->envs[env];
+    ctx->envs[env] = nullptr;
+    ctx->free_envs.push_back(env);
     return PT_OK;
 }
 
 int pt_env_read(pt_ctx* ctx, int env, int* cube_size_out, uint16_t* cube, float* pyramid) {
     if (!ctx) return PT_ERR_INVALID_ARGUMENT;
-    if (env < 0 || env >= (int)ctx->envs.size()) return ctx->fail(PT_ERR_BAD_HANDLE, "pt_env_read");
+    if (!live_env(ctx, env)) return ctx->fail(PT_ERR_BAD_HANDLE, "pt_env_read");
+    ENTER(ctx);
     HIPOK(hipStreamSynchronize(ctx->stream));
     const EnvDevice& ed = *ctx->envs[env];
     int n = ed.mip_n[0];
@@ -617,17 +857,26 @@ int pt_env_read(pt_ctx* ctx, int env, int* cube_size_out, uint16_t* cube, float*
 
 int pt_build_accel(pt_ctx* ctx) {
     if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    ENTER(ctx);
     return Pathtracer::BuildAccel(ctx);
+}
+
+int pt_accel_request_rebuild(pt_ctx* ctx) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    ctx->accel_state = ACCEL_REBUILD;
+    return PT_OK;
 }
 
 int pt_skin_run(pt_ctx* ctx, const pt_skin_params* params, const pt_bone* bones, int bone_count) {
     if (!ctx || !params) return PT_ERR_INVALID_ARGUMENT;
+    ENTER(ctx);
     return GpuSkin::Run(ctx, params, bones, bone_count);
 }
 
 int pt_trace(pt_ctx* ctx, const pt_settings* settings, const pt_execute_params* params) {
     if (!ctx || !settings || !params) return PT_ERR_INVALID_ARGUMENT;
     if (params->width == 0 || params->height == 0) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "zero resolution");
+    ENTER(ctx);
     return Pathtracer::PathtraceScene(ctx, settings, params);
 }
 
@@ -662,14 +911,23 @@ int pt_enable_counters(pt_ctx* ctx, int enable) {
     return PT_OK;
 }
 
+int pt_enable_stage_timing(pt_ctx* ctx, int enable) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    ctx->stage_timing = enable != 0;
+    if (!ctx->stage_timing) ctx->timers.used = 0;
+    return PT_OK;
+}
+
 int pt_reset_stats(pt_ctx* ctx) {
     if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    ENTER(ctx);
     HIPOK(hipMemsetAsync(ctx->d_counters, 0, sizeof(Counters), ctx->stream));
     return PT_OK;
 }
 
 int pt_get_stats(pt_ctx* ctx, pt_stats* out) {
     if (!ctx || !out) return PT_ERR_INVALID_ARGUMENT;
+    ENTER(ctx);
     HIPOK(hipStreamSynchronize(ctx->stream));
     Counters c;
     HIPOK(hipMemcpy(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
@@ -677,20 +935,26 @@ int pt_get_stats(pt_ctx* ctx, pt_stats* out) {
     out->rays_primary = c.rays_primary; out->rays_bounce = c.rays_bounce; out->rays_shadow = c.rays_shadow;
     out->rays = c.rays_primary + c.rays_bounce + c.rays_shadow;
     out->nodes_visited = c.nodes; out->tris_tested = c.tris; out->closest_hits = c.hits; out->texture_taps = c.taps;
+    out->nodes_visited_shadow = c.nodes_shadow; out->tris_tested_shadow = c.tris_shadow;
     if (ctx->have_trace) hipEventElapsedTime(&out->trace_ms, ctx->ev_trace[0], ctx->ev_trace[1]);
     if (ctx->have_accel) hipEventElapsedTime(&out->accel_ms, ctx->ev_accel[0], ctx->ev_accel[1]);
     if (ctx->have_skin) hipEventElapsedTime(&out->skin_ms, ctx->ev_skin[0], ctx->ev_skin[1]);
+    for (size_t k = 0; k < ctx->timers.used; k++) {          // per-stage times of the last pt_trace (pt_enable_stage_timing)
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ctx->timers.ev[k], ctx->timers.ev[k + 1]) == hipSuccess) out->stage_ms[ctx->timers.kind[k]] += ms;
+    }
     out->accumulated_frames = ctx->accumulated_frames;
-    if (ctx->wide_nodes == kWideNodesOnDevice)      // small scene: the build did not wait for the count (pt_host.h)
-        HIPOK(hipMemcpy(&ctx->wide_nodes, ctx->scratch.collapse_counters, 4, hipMemcpyDeviceToHost));
     out->bvh_nodes = ctx->wide_nodes;
     out->bvh_triangles = ctx->n_tris;
+    out->bvh_stack_need = ctx->stack_need;
+    out->accel_builds = ctx->accel_builds; out->accel_refits = ctx->accel_refits;
     if (c.stack_overflow) return ctx->fail(PT_ERR_CAPACITY, "traversal stack overflow: " + std::to_string(c.stack_overflow) + " pushes dropped");
     return PT_OK;
 }
 
 int pt_readback(pt_ctx* ctx, const void* device_rgba32f, uint32_t width, uint32_t height, float* host) {
     if (!ctx || !device_rgba32f || !host) return PT_ERR_INVALID_ARGUMENT;
+    ENTER(ctx);
     HIPOK(hipStreamSynchronize(ctx->stream));
     HIPOK(hipMemcpy(host, device_rgba32f, (size_t)width * height * 16, hipMemcpyDeviceToHost));
     return PT_OK;
@@ -698,17 +962,73 @@ int pt_readback(pt_ctx* ctx, const void* device_rgba32f, uint32_t width, uint32_
 
 int pt_tonemap(pt_ctx* ctx, const pt_tonemap_config* cfg, const void* device_rgba32f, uint32_t width, uint32_t height, float* host_rgb, uint8_t* host_rgba8) {
     if (!ctx || !cfg || !device_rgba32f || width == 0 || height == 0) return PT_ERR_INVALID_ARGUMENT;
-    size_t n = (size_t)width * height;
-    float* d_rgb = nullptr; uint32_t* d_q = nullptr;
-    if (host_rgb) HIPOK(hipMalloc((void**)&d_rgb, n * 12));
-    if (host_rgba8) HIPOK(hipMalloc((void**)&d_q, n * 4));
+    ENTER(ctx);
+    const size_t n = (size_t)width * height, need = n * 16;      // float RGB (12 B) + RGBA8 (4 B) per pixel, kept between calls
+    if (need > ctx->tonemap_cap) {
+        HIPOK(hipStreamSynchronize(ctx->stream));
+        hipFree(ctx->d_tonemap); ctx->d_tonemap = nullptr; ctx->tonemap_cap = 0;
+        HIPOK(hipMalloc(&ctx->d_tonemap, need));
+        ctx->tonemap_cap = need;
+    }
+    float* d_rgb = host_rgb ? (float*)ctx->d_tonemap : nullptr;
+    uint32_t* d_q = host_rgba8 ? (uint32_t*)((char*)ctx->d_tonemap + n * 12) : nullptr;
     launch_tonemap((const float4*)device_rgba32f, width, height, *cfg, d_rgb, d_q, ctx->stream);
-    hipError_t e = hipGetLastError();
-    if (!e) e = hipStreamSynchronize(ctx->stream);
-    if (!e && host_rgb) e = hipMemcpy(host_rgb, d_rgb, n * 12, hipMemcpyDeviceToHost);
-    if (!e && host_rgba8) e = hipMemcpy(host_rgba8, d_q, n * 4, hipMemcpyDeviceToHost);
-    hipFree(d_rgb); hipFree(d_q);
-    if (e) return ctx->fail(PT_ERR_DEVICE, std::string("pt_tonemap: ") + hipGetErrorString(e));
+    HIPOK(hipGetLastError());
+    HIPOK(hipStreamSynchronize(ctx->stream));
+    if (host_rgb) HIPOK(hipMemcpy(host_rgb, d_rgb, n * 12, hipMemcpyDeviceToHost));
+    if (host_rgba8) HIPOK(hipMemcpy(host_rgba8, d_q, n * 4, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+// ---- the per-frame exchange of the tile-sharded renderer (exchange.hip) ------------------------------------------------------
+int pt_exchange_unique_id(void* id_out) {
+    if (!id_out) return PT_ERR_INVALID_ARGUMENT;
+    std::string err;
+    return exchange_unique_id(id_out, err);
+}
+
+int pt_exchange_create(pt_ctx* ctx, int rank, int world, const void* unique_id) {
+    if (!ctx || world < 1 || rank < 0 || rank >= world) return PT_ERR_INVALID_ARGUMENT;
+    ENTER(ctx);
+    if (ctx->exchange) { HIPOK(hipStreamSynchronize(ctx->stream)); exchange_free(ctx->exchange); ctx->exchange = nullptr; }
+    std::string err;
+    const int rc = exchange_create(&ctx->exchange, rank, world, unique_id, err);
+    return rc == PT_OK ? PT_OK : ctx->fail(rc, err);
+}
+
+int pt_exchange_frame(pt_ctx* ctx, const void* local_image, void* frame, uint32_t width, uint32_t height, int mode, int dst_rank) {
+    if (!ctx || !local_image || width == 0 || height == 0) return PT_ERR_INVALID_ARGUMENT;
+    if (!ctx->exchange) return ctx->fail(PT_ERR_NOT_READY, "pt_exchange_frame: call pt_exchange_create first");
+    if (mode != PT_EXCHANGE_GATHER && mode != PT_EXCHANGE_REDUCE) return ctx->fail(PT_ERR_INVALID_ARGUMENT, "pt_exchange_frame: mode");
+    ENTER(ctx);
+    std::string err;
+    const int rc = exchange_frame_checked(ctx, local_image, frame, width, height, mode, dst_rank, err);
+    return rc == PT_OK ? PT_OK : ctx->fail(rc, err);
+}
+
+int pt_exchange_destroy(pt_ctx* ctx) {
+    if (!ctx) return PT_ERR_INVALID_ARGUMENT;
+    ENTER(ctx);
+    if (ctx->exchange) { HIPOK(hipStreamSynchronize(ctx->stream)); exchange_free(ctx->exchange); ctx->exchange = nullptr; }
+    return PT_OK;
+}
+
+size_t pt_tiles_packed_bytes(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_rank_count) {
+    if (tile_rank_count == 0 || tile_rank >= tile_rank_count) return 0;
+    return (size_t)tiles_of_rank(width, height, tile_rank, tile_rank_count) * 256 * 16;
+}
+
+int pt_tiles_pack(pt_ctx* ctx, const void* image, uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_rank_count, void* packed) {
+    if (!ctx || !image || !packed || width == 0 || height == 0 || tile_rank_count == 0 || tile_rank >= tile_rank_count) return PT_ERR_INVALID_ARGUMENT;
+    ENTER(ctx);
+    HIPOK(tiles_pack(image, width, height, tile_rank, tile_rank_count, packed, ctx->stream));
+    return PT_OK;
+}
+
+int pt_tiles_unpack(pt_ctx* ctx, const void* packed, uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_rank_count, void* image) {
+    if (!ctx || !image || !packed || width == 0 || height == 0 || tile_rank_count == 0 || tile_rank >= tile_rank_count) return PT_ERR_INVALID_ARGUMENT;
+    ENTER(ctx);
+    HIPOK(tiles_unpack(packed, width, height, tile_rank, tile_rank_count, image, ctx->stream));
     return PT_OK;
 }
 

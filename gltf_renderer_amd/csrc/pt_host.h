@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <string>
+#include <vector>
+
 #include "pt_types.h"
 
 namespace pt {
@@ -23,15 +26,21 @@ struct AccelScratch {
     uint32_t* kept = nullptr;        // collapse frontier (ping): binary nodes that become wide nodes
     uint32_t* widx = nullptr;        // ... and the wide-node index each was given
     uint32_t* collapse_counters = nullptr;   // greedy collapse: [0] wide nodes allocated, [1 + L] frontier size of level L
+    WideRanges* wide_ranges = nullptr;       // per wide node: the sorted-triangle range under each child (kept for accel_refit)
     size_t capacity = 0;
 };
 void accel_scratch_free(AccelScratch& s);
 // Builds the 4-wide BVH (<= n_tris nodes), the sorted intersection packets and their shading packets (n_tris each).
-// root_out: 0, or ~0 for a single triangle.  wide_nodes_out: the node count, or kWideNodesOnDevice when the build did not wait
-// for it (small scenes): it is then s.collapse_counters[0] once the stream has caught up.
-constexpr uint32_t kWideNodesOnDevice = 0xffffffffu;
+// root_out: 0, or ~0 for a single triangle.  wide_nodes_out: the node count; stack_need_out: the most traversal-stack entries any
+// ray can hold in this tree (max over nodes of the siblings pushed on the way down).  Synchronises the stream (a full build is
+// the rare event).
 hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const InstanceRec* d_instances, int n_inst, uint32_t n_tris, Bvh4Node* d_nodes,
-                       TriPacket* d_tris, ShadePacket* d_shade, int32_t* root_out, uint32_t* wide_nodes_out, hipStream_t stream);
+                       TriPacket* d_tris, ShadePacket* d_shade, int32_t* root_out, uint32_t* wide_nodes_out, uint32_t* stack_need_out, hipStream_t stream);
+// Refit after vertices or instance transforms changed (topology and triangle order kept): rewrites the intersection and shading
+// packets of the instances marked in d_touched[instance], rebuilds the segment tree over the triangles' boxes and requantises
+// every wide node from it.  Asynchronous.  Hits equal those of a full rebuild; only the tree's quality follows the old pose.
+hipError_t accel_refit(AccelScratch& s, const InstanceRec* d_instances, const uint8_t* d_touched, uint32_t n_tris, uint32_t wide_nodes,
+                       Bvh4Node* d_nodes, TriPacket* d_tris, ShadePacket* d_shade, hipStream_t stream);
 
 // ---- pt_kernel.hip: 1024 x (sin, cos) of the packed tangent angle
 hipError_t build_tangent_lut(float2* d_lut, hipStream_t stream);
@@ -71,10 +80,28 @@ struct SkinArgs {
 void launch_skin(const SkinArgs& a, bool use_mfma, hipStream_t stream);
 void launch_tonemap(const float4* in, uint32_t w, uint32_t h, const pt_tonemap_config& cfg, float* out_rgb, uint32_t* out_rgba8, hipStream_t stream);
 
-// ---- pt_kernel.hip ----------------------------------------------------------------------------
+// ---- pt_wavefront.hip / pt_kernel.hip ---------------------------------------------------------
+int traversal_stack_capacity();          // entries a ray's traversal stack holds (LDS part + scratch spill)
+// Optional per-stage timing of one wavefront launch (pt_enable_stage_timing): an event after every stage launch.
+enum { STAGE_GENERATE = 0, STAGE_TRACE = 1, STAGE_SHADE = 2, STAGE_SHADOW = 3, STAGE_RESOLVE = 4, STAGE_COUNT = 5 };
+struct StageTimers {
+    std::vector<hipEvent_t> ev;          // ev[0] = start; ev[k + 1] = after the k-th launch
+    std::vector<uint8_t> kind;           // STAGE_* of the k-th launch
+    size_t used = 0;                     // launches recorded by the last pt_trace
+};
 void launch_megakernel(const SceneRec& sc, const FrameConstants& fc, float4* output, Counters* counters, bool count, hipStream_t stream);
 size_t wavefront_workspace_bytes(uint32_t slots, int stage_blocks);
 hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4* output, Counters* counters, bool count, void* workspace,
-                            int stage_blocks, hipStream_t stream);
+                            int stage_blocks, StageTimers* timers, hipStream_t stream);
+
+// ---- exchange.hip: the per-frame tile exchange of the sharded renderer (RCCL bound at run time) ---------------------------
+struct ExchangeState;
+uint32_t tiles_of_rank(uint32_t w, uint32_t h, uint32_t rank, uint32_t world);
+hipError_t tiles_pack(const void* image, uint32_t w, uint32_t h, uint32_t rank, uint32_t world, void* packed, hipStream_t stream);
+hipError_t tiles_unpack(const void* packed, uint32_t w, uint32_t h, uint32_t rank, uint32_t world, void* image, hipStream_t stream);
+int exchange_unique_id(void* out128, std::string& err);
+int exchange_create(ExchangeState** out, int rank, int world, const void* id128, std::string& err);
+int exchange_frame(ExchangeState* x, const void* local, void* frame, uint32_t w, uint32_t h, int mode, int dst, hipStream_t stream, std::string& err);
+void exchange_free(ExchangeState* x);
 
 }  // namespace pt

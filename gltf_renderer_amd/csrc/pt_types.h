@@ -116,6 +116,9 @@ struct __attribute__((aligned(16))) Bvh4Node {
 static_assert(sizeof(Bvh4Node) == 96, "Bvh4Node");
 #endif
 constexpr int kNodeFloat4 = (int)(sizeof(Bvh4Node) / 16);
+// Per wide node, the contiguous range [first, first + count) of Morton-sorted triangles under each child (count 0: unused slot).
+// Written by the collapse, read by the refit: a child's box is a range query over the triangles' boxes.
+struct __attribute__((aligned(16))) WideRanges { uint32_t first[PT_BVH_WIDTH], count[PT_BVH_WIDTH]; };
 constexpr int32_t kEmptyChild = 0x7fffffff;
 // the plane a quantised coordinate stands for; build and traversal must use this one expression
 __host__ __device__ __forceinline__ float bvh_dequant(uint32_t q, float step, float origin) { return __builtin_fmaf((float)q, step, origin); }
@@ -206,6 +209,7 @@ struct FrameConstants {
 
 struct Counters {
     unsigned long long rays_primary, rays_bounce, rays_shadow, nodes, tris, hits, taps, stack_overflow;
+    unsigned long long nodes_shadow, tris_shadow;      // the occlusion stage's share (wavefront mode; the megakernel books everything above)
 };
 
 }  // namespace pt

@@ -272,15 +272,17 @@ PT_DEV bool slot_pixel(const FrameConstants& fc, uint32_t slot, uint32_t& px, ui
 }
 
 // wave64 reduction of the per-lane tallies, one atomic per wave per counter
+// occlusion: the node / triangle tallies go to Counters::nodes_shadow / tris_shadow (slots 8, 9) instead of nodes / tris (3, 4)
 PT_DEV void flush_counters(Counters* __restrict__ counters, uint32_t lane, unsigned n_primary, unsigned n_bounce, unsigned n_shadow, unsigned n_hits,
-                           const LaneStats& st) {
+                           const LaneStats& st, bool occlusion = false) {
     unsigned vals[8] = {n_primary, n_bounce, n_shadow, st.nodes, st.tris, n_hits, st.taps, st.overflow};
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         unsigned v = vals[k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0 && v) atomicAdd(((unsigned long long*)counters) + k, (unsigned long long)v);
+        const int slot = (occlusion && (k == 3 || k == 4)) ? k + 5 : k;
+        if (lane == 0 && v) atomicAdd(((unsigned long long*)counters) + slot, (unsigned long long)v);
     }
 }
 

@@ -320,7 +320,7 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_shadow(SceneRec s
     const ShardView sv = shard_view(wf);
     LaneStats st = {0, 0, 0, 0};
     trace_persistent<COUNT, 1>(sc, wf, s_stack + threadIdx.x, sv, 0, 0, 0xff, flags, st);
-    if (COUNT) flush_counters(counters, threadIdx.x & 63, 0, 0, 0, 0, st);
+    if (COUNT) flush_counters(counters, threadIdx.x & 63, 0, 0, 0, 0, st, true);
     else if (st.overflow) atomicAdd(&counters->stack_overflow, (unsigned long long)st.overflow);
 }
 
@@ -386,15 +386,36 @@ static WfBuffers carve(void* base, uint32_t slots, int stage_blocks) {
     return wf;
 }
 
+int traversal_stack_capacity() { return kStackLds + kStackSpill; }
+
 hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4* output, Counters* counters, bool count, void* workspace,
-                            int stage_blocks, hipStream_t stream) {
+                            int stage_blocks, StageTimers* timers, hipStream_t stream) {
+    if (timers) timers->used = 0;
     if (fc.my_tiles == 0) return hipSuccess;
+    // pt_enable_stage_timing: an event after every launch, so that the time of a launch can be split by stage (diagnostic: the
+    // events cost a few microseconds each)
+    auto event_at = [&](size_t i) -> hipEvent_t {
+        while (timers->ev.size() <= i) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return nullptr; timers->ev.push_back(e); }
+        return timers->ev[i];
+    };
+    auto mark = [&](int kind) {                              // the launch just enqueued was of stage `kind`
+        if (!timers) return;
+        const size_t k = timers->used;
+        hipEvent_t ev = event_at(k + 1);
+        if (!ev) return;
+        if (timers->kind.size() < k + 1) timers->kind.resize(k + 1);
+        timers->kind[k] = (uint8_t)kind;
+        hipEventRecord(ev, stream);
+        timers->used = k + 1;
+    };
     const uint32_t slots = fc.my_tiles * kBlock * fc.spp;
     WfBuffers wf = carve(workspace, slots, stage_blocks);
     hipError_t e = hipMemsetAsync(wf.cnt[0], 0, (size_t)5 * kShards * kCounterStride * 4, stream);     // the five counter arrays are contiguous
     if (e) return e;
     const dim3 block(kBlock), full(fc.my_tiles), stage(kShards * wf.blocks_per_shard);
+    if (timers) { hipEvent_t ev = event_at(0); if (ev) hipEventRecord(ev, stream); else timers = nullptr; }
     hipLaunchKernelGGL(k_wf_generate, stage, block, 0, stream, fc, wf, counters);
+    mark(STAGE_GENERATE);
     const uint32_t flags = fc.flags;
     const int iterations = fc.debug_output != PT_DEBUG_OUTPUT_NONE ? 1 : fc.max_bounces + 1;
     for (int b = 0; b < iterations; b++) {
@@ -407,11 +428,15 @@ hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4
         }
         if (count) hipLaunchKernelGGL(k_wf_trace<true>, stage, block, 0, stream, sc, wf, cur, rf, rmask, counters);
         else hipLaunchKernelGGL(k_wf_trace<false>, stage, block, 0, stream, sc, wf, cur, rf, rmask, counters);
+        mark(STAGE_TRACE);
         hipLaunchKernelGGL(k_wf_shade, stage, block, 0, stream, sc, fc, wf, cur, counters);
+        mark(STAGE_SHADE);
         if (count) hipLaunchKernelGGL(k_wf_shadow<true>, stage, block, 0, stream, sc, wf, flags, counters);
         else hipLaunchKernelGGL(k_wf_shadow<false>, stage, block, 0, stream, sc, wf, flags, counters);
+        mark(STAGE_SHADOW);
     }
     hipLaunchKernelGGL(k_wf_resolve, full, block, 0, stream, fc, wf, output);
+    mark(STAGE_RESOLVE);
     return hipGetLastError();
 }
 

@@ -49,16 +49,19 @@ __global__ __launch_bounds__(64) void k_skin(SkinArgs a) {
         uint4 bw = a.in_joint_weight[index];
         uint32_t ids[4] = {bw.x & 0xffff, bw.x >> 16, bw.y & 0xffff, bw.y >> 16};
         float w[4] = {(float)(bw.z & 0xffff) / 65535.0f, (float)(bw.z >> 16) / 65535.0f, (float)(bw.w & 0xffff) / 65535.0f, (float)(bw.w >> 16) / 65535.0f};
+        // A joint id beyond the bone array reads zeros upstream (D3D12 robust buffer access on the structured buffer,
+        // Skin.cs.hlsl:93-101): a zero matrix, i.e. no contribution.  Here it must not become a raw out-of-bounds load.
+        const uint32_t nb = (uint32_t)a.bone_count;
         vec3 sp = v3(0);
 #pragma unroll
-        for (int i = 0; i < 4; i++) sp += w[i] * mul_point(a.bones[ids[i]].transform, position);
+        for (int i = 0; i < 4; i++) if (ids[i] < nb) sp += w[i] * mul_point(a.bones[ids[i]].transform, position);
         position = sp;
         if (a.input_mesh_flags & PT_MESH_FLAG_TANGENT_SPACE) {
             vec3 sn = v3(0), stn = v3(0);
 #pragma unroll
-            for (int i = 0; i < 4; i++) sn += w[i] * mul_dir(a.bones[ids[i]].inverse_transpose, normal);
+            for (int i = 0; i < 4; i++) if (ids[i] < nb) sn += w[i] * mul_dir(a.bones[ids[i]].inverse_transpose, normal);
 #pragma unroll
-            for (int i = 0; i < 4; i++) stn += w[i] * mul_dir(a.bones[ids[i]].transform, tangent);
+            for (int i = 0; i < 4; i++) if (ids[i] < nb) stn += w[i] * mul_dir(a.bones[ids[i]].transform, tangent);
             normal = sn; tangent = stn;
         }
     }

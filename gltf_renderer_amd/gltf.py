@@ -12,7 +12,7 @@ from .renderer import MiptError, load_library
 SCENE_EXPORTS = ["gs_load_file", "gs_free", "gs_last_error", "gs_get_counts", "gs_get_primitive", "gs_get_morph_target", "gs_get_material",
                  "gs_get_texture", "gs_get_sampler", "gs_get_node", "gs_get_node_weights", "gs_get_scene_nodes", "gs_get_skin", "gs_get_animation",
                  "gs_get_channel", "gs_sample_channel", "gs_apply_rest_transforms", "gs_animate", "gs_calculate_global_transforms", "gs_player_tick",
-                 "gs_gather_lights", "gs_gather_bones", "gs_upload", "gs_frame", "img_load_rgba8", "img_decode_rgba8", "img_load_rgb32f",
+                 "gs_gather_lights", "gs_gather_bones", "gs_upload", "gs_unload", "gs_frame", "img_load_rgba8", "img_decode_rgba8", "img_load_rgb32f",
                  "img_decode_rgb32f", "img_free", "img_write_png", "img_write_pfm", "img_write_exr"]
 
 
@@ -220,6 +220,10 @@ class GltfScene:
     def upload(self, renderer):
         """Create the scene's streams / textures / samplers in a Renderer's context (pt_ctx)."""
         self._ck(self.L.gs_upload(self.h, renderer.h))
+
+    def unload(self, renderer):
+        """Gltf::Unload: empty the context's instance / material tables and destroy everything upload() created."""
+        self._ck(self.L.gs_unload(self.h, renderer.h))
 
     def frame(self, renderer, scene=0):
         """One frame of host work: skin, gather lights + materials, rebuild the instance table.  Returns light_count."""

@@ -19,7 +19,11 @@ EXPORTS = ["pt_abi_version", "pt_create", "pt_destroy", "pt_last_error", "pt_buf
            "pt_texture_create", "pt_sampler_create", "pt_scene_set_materials", "pt_scene_set_lights", "pt_scene_set_instances",
            "pt_env_create", "pt_env_read", "pt_build_accel", "pt_skin_run", "pt_trace", "pt_set_bounce_limit", "pt_set_samples_per_trace", "pt_set_null_shadow_culling", "pt_enable_counters",
            "pt_set_kernel_mode",
-           "pt_get_stats", "pt_reset_stats", "pt_readback", "pt_tonemap"]
+           "pt_get_stats", "pt_reset_stats", "pt_readback", "pt_tonemap",
+           # ABI 2
+           "pt_buffer_destroy", "pt_texture_destroy", "pt_env_destroy", "pt_accel_request_rebuild", "pt_enable_stage_timing",
+           "pt_exchange_unique_id", "pt_exchange_create", "pt_exchange_frame", "pt_exchange_destroy",
+           "pt_tiles_packed_bytes", "pt_tiles_pack", "pt_tiles_unpack"]
 
 
 class MiptError(RuntimeError):
@@ -43,7 +47,7 @@ def load_library():
     missing = [s for s in EXPORTS if not hasattr(L, s)]
     if missing:
         raise MiptError("libmipt.so lacks symbols declared in include/mipt.h: %s" % missing)
-    if L.pt_abi_version() != 1:
+    if L.pt_abi_version() != 2:
         raise MiptError("libmipt.so ABI version mismatch")
     vp, ci = C.c_void_p, C.c_int
     L.pt_create.argtypes = [ci, vp, vp, C.POINTER(vp)]
@@ -73,6 +77,19 @@ def load_library():
     L.pt_reset_stats.argtypes = [vp]
     L.pt_readback.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp]
     L.pt_tonemap.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp]
+    L.pt_buffer_destroy.argtypes = [vp, ci]
+    L.pt_texture_destroy.argtypes = [vp, ci]
+    L.pt_env_destroy.argtypes = [vp, ci]
+    L.pt_accel_request_rebuild.argtypes = [vp]
+    L.pt_enable_stage_timing.argtypes = [vp, ci]
+    L.pt_exchange_unique_id.argtypes = [vp]
+    L.pt_exchange_create.argtypes = [vp, ci, ci, vp]
+    L.pt_exchange_frame.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, ci, ci]
+    L.pt_exchange_destroy.argtypes = [vp]
+    L.pt_tiles_packed_bytes.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.pt_tiles_packed_bytes.restype = C.c_size_t
+    L.pt_tiles_pack.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    L.pt_tiles_unpack.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     _LIB = L
     return L
 
@@ -140,6 +157,15 @@ class Renderer:
         self._check(self.L.pt_buffer_read(self.h, handle, _p(out), out.nbytes))
         return out
 
+    def buffer_destroy(self, handle):
+        self._check(self.L.pt_buffer_destroy(self.h, handle))
+
+    def texture_destroy(self, handle):
+        self._check(self.L.pt_texture_destroy(self.h, handle))
+
+    def env_destroy(self, env):
+        self._check(self.L.pt_env_destroy(self.h, env))
+
     def texture_create(self, rgba8, srgb):
         a = np.ascontiguousarray(rgba8, dtype=np.uint8)
         h, w = a.shape[:2]
@@ -202,7 +228,50 @@ class Renderer:
         self._check(self.L.pt_set_kernel_mode(self.h, mode, stage_blocks))
 
     def build_accel(self):
+        """Full build, refit or nothing, whichever the changes since the last call ask for (include/mipt.h pt_build_accel)."""
         self._check(self.L.pt_build_accel(self.h))
+
+    def request_rebuild(self):
+        self._check(self.L.pt_accel_request_rebuild(self.h))
+
+    def enable_stage_timing(self, on):
+        self._check(self.L.pt_enable_stage_timing(self.h, int(bool(on))))
+
+    # ---- multi-GPU exchange (RCCL inside libmipt.so; the unique id travels by whatever transport the host has)
+    def exchange_unique_id(self):
+        buf = (C.c_ubyte * abi.EXCHANGE_ID_BYTES)()
+        rc = self.L.pt_exchange_unique_id(buf)
+        if rc != 0:
+            raise MiptError("pt_exchange_unique_id failed: %d (RCCL not loadable?)" % rc)
+        return bytes(buf)
+
+    def exchange_create(self, rank, world, unique_id=None):
+        buf = None if unique_id is None else (C.c_ubyte * abi.EXCHANGE_ID_BYTES).from_buffer_copy(unique_id)
+        self._check(self.L.pt_exchange_create(self.h, rank, world, buf))
+
+    def exchange_frame(self, local, frame=None, mode=abi.EXCHANGE_GATHER, dst=0):
+        """local: this rank's accumulation image (H, W, 4) CUDA tensor, only read.  frame: where the root assembles the frame
+        (None = in place over the other ranks' tiles of `local`).  Asynchronous on the context's stream."""
+        h, w = local.shape[:2]
+        self._check(self.L.pt_exchange_frame(self.h, C.c_void_p(local.data_ptr()), C.c_void_p(frame.data_ptr()) if frame is not None else None, w, h, mode, dst))
+
+    def exchange_destroy(self):
+        self._check(self.L.pt_exchange_destroy(self.h))
+
+    def tiles_packed_bytes(self, width, height, rank, world):
+        return int(self.L.pt_tiles_packed_bytes(width, height, rank, world))
+
+    def tiles_pack(self, image, rank, world):
+        h, w = image.shape[:2]
+        n = self.tiles_packed_bytes(w, h, rank, world) // 16
+        packed = self.torch.empty((max(n, 1), 4), dtype=self.torch.float32, device=image.device)
+        self._check(self.L.pt_tiles_pack(self.h, C.c_void_p(image.data_ptr()), w, h, rank, world, C.c_void_p(packed.data_ptr())))
+        return packed[:n]
+
+    def tiles_unpack(self, packed, image, rank, world):
+        h, w = image.shape[:2]
+        assert packed.numel() * 4 >= self.tiles_packed_bytes(w, h, rank, world)
+        self._check(self.L.pt_tiles_unpack(self.h, C.c_void_p(packed.data_ptr()), w, h, rank, world, C.c_void_p(image.data_ptr())))
 
     def skin_run(self, params, bones):
         if bones is None or len(bones) == 0:

@@ -27,6 +27,7 @@ class SceneData:
         self.env_image = None  # equirect float32 HxWx3
         self.world_to_view = camera.orbit_world_to_view()
         self.y_fov, self.z_near, self.z_far = math.pi / 2, 0.01, 100.0
+        self.ortho = None      # (x_mag, y_mag): Camera::Orthographic (Camera.h:31-40) instead of the perspective camera
         self.width, self.height = 256, 256
         self.settings = PtSettings.app_defaults()
         self.bounce_limit = abi.REFERENCE_MAX_BOUNCES
@@ -99,7 +100,10 @@ class SceneData:
     def execute_params(self, frame=0, tile_rank=0, tile_rank_count=1, env_handle=None):
         p = PtExecuteParams()
         p.world_to_view[:] = camera.cm(self.world_to_view)
-        p.view_to_clip[:] = camera.cm(camera.view_to_clip(self.width / self.height, self.y_fov, self.z_near, self.z_far))
+        if self.ortho is not None:
+            p.view_to_clip[:] = camera.cm(camera.ortho_view_to_clip(self.ortho[0], self.ortho[1], self.z_near, self.z_far))
+        else:
+            p.view_to_clip[:] = camera.cm(camera.view_to_clip(self.width / self.height, self.y_fov, self.z_near, self.z_far))
         p.width, p.height = self.width, self.height
         p.frame = frame
         p.light_count = len(self.lights)

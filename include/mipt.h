@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MIPT_ABI_VERSION 1
+#define MIPT_ABI_VERSION 2
 
 typedef enum pt_status {
     PT_OK = 0,
@@ -313,6 +313,14 @@ typedef struct pt_stats {
     float    skin_ms;           /* last pt_skin_run */
     int32_t  accumulated_frames;
     uint32_t bvh_nodes, bvh_triangles;
+    /* ABI 2 */
+    uint64_t nodes_visited_shadow;   /* the occlusion stage's share of nodes_visited / tris_tested (wavefront mode, counters on) */
+    uint64_t tris_tested_shadow;
+    float    stage_ms[5];       /* last pt_trace with pt_enable_stage_timing(1): generate, closest-hit trace, shade, shadow trace,
+                                   resolve -- summed over the bounces of the launch */
+    uint32_t bvh_stack_need;    /* most traversal-stack entries any ray can hold in the current tree (build-time bound) */
+    uint32_t accel_builds;      /* full builds / refits since pt_create */
+    uint32_t accel_refits;
 } pt_stats;
 
 typedef struct pt_ctx pt_ctx;
@@ -332,6 +340,11 @@ int pt_abi_version(void);
 int pt_buffer_create(pt_ctx* ctx, const void* host, size_t bytes, int format, int* handle_out);
 int pt_buffer_update(pt_ctx* ctx, int handle, const void* host, size_t bytes);
 int pt_buffer_read(pt_ctx* ctx, int handle, void* host, size_t bytes);
+/* Gltf::Unload (Source/Gltf.cpp:123-157; called before the next scene loads, Source/Main.cpp:43-54): release one stream / texture.
+ * Fails with PT_ERR_NOT_READY while the current instance table (buffers) or material table (textures) still refers to it --
+ * replace those tables first, as the reference's per-frame tables are rebuilt from the new scene.  Handles are reused. */
+int pt_buffer_destroy(pt_ctx* ctx, int handle);
+int pt_texture_destroy(pt_ctx* ctx, int handle);
 /* Gltf::LoadTexture (Source/Gltf.cpp:1047-1078): RGBA8, one mip, optional sRGB view. */
 int pt_texture_create(pt_ctx* ctx, const uint8_t* rgba8, int width, int height, int srgb, int* handle_out);
 /* Gltf::LoadSamplers (Source/Gltf.cpp:935, TinyGltfTools.h:16-43). Handle 0 pre-exists. */
@@ -349,10 +362,20 @@ int pt_env_create(pt_ctx* ctx, const float* equirect_rgb32f, int width, int heig
 /* Test hook: copy out the preprocessed maps.  cube_rgba16f: 6*N*N*4 halfs of mip 0 (may be NULL);
  * importance: the whole pyramid, level 0 first (may be NULL).  Sizes via the out params. */
 int pt_env_read(pt_ctx* ctx, int env, int* cube_size_out, uint16_t* cube_rgba16f, float* importance_pyramid);
+/* EnvironmentMap::Destroy (the reference replaces its one environment in place, Source/EnvironmentMap.cpp:84-130). */
+int pt_env_destroy(pt_ctx* ctx, int env);
 
 /* BuildAllBlas / UpdateAllBlas / BuildTlas (Source/Pathtracer.cpp:138-257).  Called implicitly
- * by pt_trace when the scene is dirty; exposed so it can be timed on its own. */
+ * by pt_trace when the scene is dirty; exposed so it can be timed on its own.
+ *   - a new set of triangles (instance count, index counts) -> full build: Morton sort, LBVH, 4-wide collapse;
+ *   - only vertices moved (pt_skin_run, pt_buffer_update) or instance rows changed (transform, flags) -> REFIT, like
+ *     UpdateDynamicBlas (Source/RayTracingAccelerationStructure.cpp:110-158): topology and triangle order stay, the touched
+ *     instances' packets are rewritten and every box re-derived.  Hits equal a full rebuild's; the tree's quality follows the
+ *     pose it was built for, as upstream's refitted BLAS does (upstream never rebuilds one);
+ *   - an instance table identical to the current one -> nothing.
+ * pt_accel_request_rebuild forces the next call to build from scratch (e.g. after a pose has drifted far from the built one). */
 int pt_build_accel(pt_ctx* ctx);
+int pt_accel_request_rebuild(pt_ctx* ctx);
 
 /* GpuSkin::Run (Source/GpuSkin.cpp:57-118).  bones may be NULL (no skinning, quirk q19 kept). */
 int pt_skin_run(pt_ctx* ctx, const pt_skin_params* params, const pt_bone* bones, int bone_count);
@@ -376,6 +399,7 @@ int pt_set_samples_per_trace(pt_ctx* ctx, int samples);
  * counts drop.  Default 0, so that rays-per-frame and Mrays/s mean what they mean for the reference. */
 int pt_set_null_shadow_culling(pt_ctx* ctx, int enable);
 int pt_enable_counters(pt_ctx* ctx, int enable);      /* node / triangle / tap counters (slower) */
+int pt_enable_stage_timing(pt_ctx* ctx, int enable);  /* pt_stats.stage_ms: an event after every stage launch (diagnostic) */
 /* Kernel arrangement (same per-vertex code, same results up to fp32 accumulation order): PT_MODE_WAVEFRONT (default) =
  * staged trace / shade / shadow kernels over SoA ray queues in HBM with ballot compaction; PT_MODE_MEGAKERNEL = one
  * lane per pixel-sample for the whole path.  stage_blocks: workgroups per wavefront stage launch (<= 0 keeps the current setting; the
@@ -393,6 +417,29 @@ int pt_readback(pt_ctx* ctx, const void* device_rgba32f, uint32_t width, uint32_
  * float RGB (pre-quantisation, what the parity metric uses) and/or RGBA8; either may be NULL. */
 int pt_tonemap(pt_ctx* ctx, const pt_tonemap_config* config, const void* device_rgba32f,
                uint32_t width, uint32_t height, float* host_rgb32f, uint8_t* host_rgba8);
+
+/* ---- multi-GPU: the one exchange per output frame (new capability; the reference is single-GPU) -------------
+ * One process per GPU, scene replicated, rank r renders tiles t % world == r (pt_execute_params.tile_rank / tile_rank_count)
+ * into ITS OWN full-size accumulation image; per reported frame pt_exchange_frame assembles the image on rank dst_rank with one
+ * RCCL exchange on the context's stream (asynchronous).  RCCL is bound at run time (librccl.so.1); PT_ERR_NOT_READY if absent.
+ *   PT_EXCHANGE_GATHER  own tiles packed (1/N of the image), grouped ncclSend / ncclRecv to the root over direct xGMI links,
+ *                       unpacked into `frame`: bit-identical to a 1-rank frame.
+ *   PT_EXCHANGE_REDUCE  ncclReduce(sum) of a zero-masked copy (own tiles, zeros elsewhere) into `frame`.
+ * `local_image` is this rank's accumulation image and is only read, so accumulation composes with the exchange; `frame` is
+ * written on the root only (NULL or == local_image: assemble in place over the other ranks' tiles, which the root never renders).
+ * pt_exchange_unique_id: ncclGetUniqueId on one rank; the host hands the PT_EXCHANGE_ID_BYTES to every rank (file, socket, MPI,
+ * torch.distributed ...).  world == 1 with unique_id NULL creates no communicator (the frame is the local image). */
+#define PT_EXCHANGE_ID_BYTES 128
+enum { PT_EXCHANGE_GATHER = 0, PT_EXCHANGE_REDUCE = 1 };
+int pt_exchange_unique_id(void* id_out);
+int pt_exchange_create(pt_ctx* ctx, int rank, int world, const void* unique_id);
+int pt_exchange_frame(pt_ctx* ctx, const void* local_image, void* frame, uint32_t width, uint32_t height, int mode, int dst_rank);
+int pt_exchange_destroy(pt_ctx* ctx);
+/* The transport-free halves of the gather, for hosts with their own transport (and the tests): a rank's tiles in slot order,
+ * 256 float4 per 16x16 tile (pixels outside a ragged edge tile pack as zeros). */
+size_t pt_tiles_packed_bytes(uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_rank_count);
+int pt_tiles_pack(pt_ctx* ctx, const void* image, uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_rank_count, void* packed_device);
+int pt_tiles_unpack(pt_ctx* ctx, const void* packed_device, uint32_t width, uint32_t height, uint32_t tile_rank, uint32_t tile_rank_count, void* image);
 
 #ifdef __cplusplus
 }

@@ -100,6 +100,9 @@ int gs_gather_bones(const gs_scene* s, int node, pt_bone* out, int capacity);
 
 /* Create every stream, texture, sampler and dynamic-mesh output of the scene in the path-tracing context. */
 int gs_upload(gs_scene* s, pt_ctx* ctx);
+/* Gltf::Unload (Gltf.cpp:123-157; Main.cpp:43-54 calls it before the next scene is loaded): empties the context's instance and
+ * material tables and destroys every stream, dynamic-mesh output and texture gs_upload created.  The scene can be uploaded again. */
+int gs_unload(gs_scene* s, pt_ctx* ctx);
 /* One frame of host work (Renderer.cpp:293-330): PerformSkinning (pt_skin_run per dynamic primitive), GatherLights ->
  * pt_scene_set_lights, GatherMaterials -> pt_scene_set_materials, BuildTlas' instance walk -> pt_scene_set_instances.
  * Global transforms must be current.  light_count_out feeds pt_execute_params.light_count. */

@@ -1008,7 +1008,12 @@ struct SkinParams {
     uint32_t num_of_vertices, input_mesh_flags, output_mesh_flags; int input_position, input_tangent_space, input_joint_weight,
         output_position, output_tangent_space, num_of_morph_targets; float morph_weights[4]; int morph_position[4], morph_tangent_space[4]; int use_mfma;
 };
-static void skin_run(Oracle& o, const SkinParams& sp, const Bone* bones) {
+// bone_count: StructuredBuffer<Bone> reads beyond the buffer return zeros under D3D12 robust buffer access (Skin.cs.hlsl:93-101 index
+// the buffer with the vertex's raw joint ids): an out-of-range joint contributes a zero matrix.
+static void skin_run(Oracle& o, const SkinParams& sp, const Bone* bones_in, int bone_count) {
+    static const Bone zero_bone = {};
+    auto bone_at = [&](uint32_t id) -> const Bone& { return id < (uint32_t)bone_count ? bones_in[id] : zero_bone; };
+    const Bone* bones = bones_in;
     uint32_t in_flags = sp.input_mesh_flags;
     if (!bones) in_flags &= (uint32_t)!(1u << 5);          // GpuSkin.cpp:94: `&= !FLAG` clears ALL flags (quirk q19)
     int nt = std::min(sp.num_of_morph_targets, 4);
@@ -1035,14 +1040,14 @@ static void skin_run(Oracle& o, const SkinParams& sp, const Bone* bones) {
                 w[2 * i] = (float)(bw[2 + i] & 0xffff) / 65535.0f; w[2 * i + 1] = (float)(bw[2 + i] >> 16) / 65535.0f;
             }
             float3 sp_pos = {0, 0, 0};
-            for (int i = 0; i < 4; i++) sp_pos += w[i] * xyz(mul(bones[ids[i]].transform, F4(position, 1.f)));
+            for (int i = 0; i < 4; i++) sp_pos += w[i] * xyz(mul(bone_at(ids[i]).transform, F4(position, 1.f)));
             position = sp_pos;
             if (in_flags & (1u << 1)) {
                 float3 sn = {0, 0, 0};
-                for (int i = 0; i < 4; i++) sn += w[i] * xyz(mul(bones[ids[i]].inverse_transpose, F4(normal, 0.f)));
+                for (int i = 0; i < 4; i++) sn += w[i] * xyz(mul(bone_at(ids[i]).inverse_transpose, F4(normal, 0.f)));
                 normal = sn;
                 float3 st = {0, 0, 0};
-                for (int i = 0; i < 4; i++) st += w[i] * xyz(mul(bones[ids[i]].transform, F4(xyz(tangent), 0.f)));
+                for (int i = 0; i < 4; i++) st += w[i] * xyz(mul(bone_at(ids[i]).transform, F4(xyz(tangent), 0.f)));
                 tangent = {st.x, st.y, st.z, tangent.w};
             }
         }
@@ -1153,7 +1158,7 @@ void orc_env_read(void* h, int env, uint16_t* cube_rgba16f, float* pyramid) {
 void orc_set_bounce_limit(void* h, int limit) { ((Oracle*)h)->bounce_limit = limit; }
 void orc_set_brute_force(void* h, int on) { ((Oracle*)h)->brute_force = on != 0; }
 void orc_build_accel(void* h) { build_accel(*(Oracle*)h); }
-void orc_skin_run(void* h, const void* params, const void* bones) { skin_run(*(Oracle*)h, *(const SkinParams*)params, (const Bone*)bones); }
+void orc_skin_run(void* h, const void* params, const void* bones, int bone_count) { skin_run(*(Oracle*)h, *(const SkinParams*)params, (const Bone*)bones, bone_count); }
 void orc_trace(void* h, const void* settings, const void* params, int nthreads) { pathtrace_scene(*(Oracle*)h, *(const Settings*)settings, *(const ExecuteParams*)params, nthreads); }
 // out[0..6] = primary, bounce, shadow, nodes, tris, closest hits, texture taps; out[7] = accumulated_frames
 void orc_get_counters(void* h, uint64_t* out, int reset) {

@@ -47,7 +47,7 @@ def lib():
         L.orc_env_read.restype = None
         L.orc_set_bounce_limit.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_brute_force.argtypes = [C.c_void_p, C.c_int]
-        L.orc_skin_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_skin_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_trace.restype = None
         L.orc_get_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -187,10 +187,10 @@ class Oracle:
 
     def skin_run(self, params, bones):
         if bones is None or len(bones) == 0:
-            self.L.orc_skin_run(self.h, C.byref(params), None)
+            self.L.orc_skin_run(self.h, C.byref(params), None, 0)
         else:
             arr = (abi.PtBone * len(bones))(*bones)
-            self.L.orc_skin_run(self.h, C.byref(params), C.byref(arr))
+            self.L.orc_skin_run(self.h, C.byref(params), C.byref(arr), len(bones))
 
     def trace(self, settings, params, output, nthreads=None):
         """output: float32 array (H, W, 4), modified in place (the accumulation target)."""

@@ -30,7 +30,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), "libmipt.so does not export %s" % s
     assert sorted(renderer.EXPORTS) == syms
-    assert L.pt_abi_version() == 1
+    assert L.pt_abi_version() == 2
     # the scene side (include/mipt_scene.h): loader, animation, image readers
     from gltf_renderer_amd import gltf
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mipt_scene.h")).read(), flags=re.S)
