@@ -1,40 +1,39 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mrays/s + ms/frame of the path-tracing hot path on MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched under
-torch.distributed.run, one rank per GPU.  A "step" = one pt_trace of the whole frame (1 sample per
-pixel, BASELINE.json metric) on the Sponza-class stand-in (configs[2]: 1920x1080, 8 bounces + RR,
-punctual lights + env MIS).  With N ranks the frame is sharded by 16x16 pixel tile (tile t -> rank
-t % N), every rank renders its tiles and ONE exchange per frame assembles the image on rank 0: by
-default each rank sends only its own tiles point to point over its direct xGMI link (--exchange gather),
-or an RCCL reduce(sum) of the zeroed full-size image (--exchange reduce); tiles are disjoint, so both
-give the same bits.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched under torch.distributed.run, one rank per
+GPU.  Workload = BASELINE.json configs[2], the config the metric "@1920x1080, 8-bounce" is quoted on: the Sponza-class stand-in,
+1920x1080, 8 bounces + RR, punctual lights + env MIS (configs[1], [3], [4] are parity-test cases: tests/test_gpu_round2.py).
 
-Samples per step.  One pt_trace carries a SAMPLE BATCH (pt_set_samples_per_trace): S samples per pixel in
-one set of kernel launches, bit-identical to S consecutive reference frames (tested).  An offline path
-tracer accumulates hundreds of samples, and a batch keeps 256 CUs full through the thin late bounces:
-1080p on one MI355X goes from 2.56 Grays/s at S = 1 to 3.29 at S = 8 (3.48 at 32).  Default S = 8 per GPU;
-`config.ms_per_1spp_frame` is the step time / S and `config.ms_single_sample_launch` the latency of an
-S = 1 launch, measured beside it.
+A STEP is one `pt_trace` of the whole frame carrying a SAMPLE BATCH of 8 samples per pixel (pt_set_samples_per_trace): one set
+of kernel launches, bit-identical to 8 consecutive reference frames (tested).  The reference renders one sample per
+PathtraceScene call because it presents every frame; an offline renderer accumulates hundreds, and a batch keeps 256 CUs full
+through the thin late bounces.  The reference-semantics figure -- one 1-spp `pt_trace`, SURVEY 8(d) -- is reported beside it as
+`config.ms_single_sample_launch` (median of >= 20 launches after 3 warm-ups) with `config.mrays_single_sample_launch`.
 
-Scaling (N > 1).  Default "weak": a step accumulates 8 x N samples per pixel of the tile-sharded frame, so
-every rank keeps the work of a 1-GPU step (1/N of the tiles x 8N samples) in ONE batch - a 1/N tile shard
-of a single sample cannot fill a 256-CU GPU (measured: 0.99 Grays/s per GPU at N = 8), a batch can (2.5) -
-then one exchange of the accumulated tiles.  `--scaling strong` keeps 8 samples per pixel per step split N
-ways (total work fixed).  The JSON line says which.
+N > 1: the frame is sharded by 16x16 pixel tile (tile t -> rank t % N), every rank renders its tiles into ITS OWN accumulation
+image, and ONE exchange per step assembles the frame on rank 0 -- `pt_exchange_frame` inside libmipt.so (RCCL on the launch
+stream: every rank sends its own tiles point to point over its direct xGMI link, or `--exchange reduce`: ncclReduce of a
+zero-masked copy).  The headline line is STRONG scaling: the same 8-spp step split N ways (total work fixed, the BASELINE metric
+on N GPUs).  The same run then times the WEAK variant (8 x N samples per step: per-GPU work fixed) and reports it in
+`weak_scaling`.  `--backend gloo --single-device` rehearses the rank logic on one GPU through the torch.distributed test double
+(gltf_renderer_amd/sharding.py); RCCL itself needs one GPU per rank.
 
-Timed region: inputs (scene, BVH, textures, env maps) are resident in HBM; K steps bracketed by
-barrier + torch.cuda.synchronize on both sides; time = max over ranks.  value = rays traced by all
-ranks in the K steps / that time.  Rays are counted by the kernel itself (every traversal started).
+Timed region: inputs (scene, BVH, textures, env maps) resident in HBM; K steps bracketed by barrier + torch.cuda.synchronize on
+both sides; time = max over ranks; value = rays traced by all ranks in the K steps / that time.  Rays are counted by the kernels
+(every traversal started).  The accumulation is reset before it could reach max_accumulated_frames, so no timed step is a no-op.
 
-Extra objects on the JSON line:
-  roofline     - the wavefront pipeline of one pt_trace (one launch = one step = S samples): algorithmic bytes per
-                 launch (counted by an untimed instrumented replay of the same K frames: nodes*64 +
-                 tris*48 + hits*S_hit + taps*16 + env loads + 32 B/pixel) / mean per-frame kernel time
-                 measured live with HIP events on the launch stream; peak = 8 TB/s HBM; traffic =
-                 PMC-measured HBM bytes per launch from profiles/pmc_traffic.json (same command), or null.
-  cpu_baseline - the CPU oracle (kind "port": the reference has no CPU tracer) on a bounded sample of
-                 the same workload, all host cores.
+Extra objects on the JSON line (rank 0, N = 1):
+  roofline     - for the DOMINANT KERNEL of the pipeline (the stage with the largest share of a launch's time): achieved =
+                 its algorithmic bytes per launch / its time per launch (HIP events after every stage launch on the launch
+                 stream, untimed replay of the same frames without counters); peak = 8 TB/s.  `stages` holds the same for every
+                 stage with the roof that applies to it (cache-gather ceilings of MI355X_MICROARCH.md for the traversal stages),
+                 LDS-resident table bytes and fetched bytes apart; `pipeline` the whole launch.  `traffic` = PMC-measured HBM
+                 bytes of that kernel per launch from profiles/ (separate rocprofv3 --pmc passes), `traffic_source` says which file.
+  cpu_baseline - the CPU oracle (kind "port": the reference has no CPU tracer and no CPU BVH build) on a bounded sample of the same
+                 workload: all-core and 1-thread Mrays/s with the CPU model, plus `legs`: B2 CPU LBVH build vs the HIP build and
+                 refit, B3 the restated per-frame host work (gs_animate + global transforms + gs_frame) in microseconds, B4 CPU
+                 skinning vs the HIP kernels.
 """
 import argparse
 import json
@@ -45,13 +44,30 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SPP_PER_STEP = 8            # samples per pixel per step of the headline line
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def median(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="sponza", choices=["sponza", "helmet", "grid", "figure", "test"])
+    ap.add_argument("--config", default="sponza", choices=["sponza", "helmet", "grid", "figure", "sponza_figure", "test"])
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -59,16 +75,14 @@ def main():
     ap.add_argument("--save-image", default="")
     ap.add_argument("--mode", default="wavefront", choices=["wavefront", "megakernel"])
     ap.add_argument("--stage-blocks", type=int, default=0)
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --single-device rehearses N ranks on a 1-GPU box")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo + --single-device rehearses N ranks on a 1-GPU box through the test double")
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (RCCL needs one device per rank)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = every step accumulates N samples per pixel of the tile-sharded frame in one sample batch (per-GPU work fixed); "
-                         "strong = every step is one sample per pixel split N ways (total work fixed)")
-    ap.add_argument("--spp", type=int, default=0,
-                    help="samples per pixel per step (sample batch, pt_set_samples_per_trace); default 8 on one GPU, 8 x N with --scaling weak (max 64)")
-    ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"], help="per-frame assembly on rank 0: own-tile gather (default) or full-image reduce")
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step (sample batch); default 8")
+    ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"], help="per-step assembly on rank 0: own-tile gather (default) or reduce of the zero-masked copy")
+    ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the second (weak-scaling) timed loop")
     ap.add_argument("--cull-null-shadow", action="store_true", help="experiment: pt_set_null_shadow_culling(1) -- same image, fewer shadow rays than the reference traces (off for the headline line)")
-    ap.add_argument("--animate", action="store_true", help="config 5 (--config figure): skin -> BVH rebuild -> trace every step, accumulation reset each frame")
+    ap.add_argument("--animate", action="store_true", help="dynamic path (--config figure / sponza_figure): skin -> BVH refit -> trace every step, accumulation reset each frame")
+    ap.add_argument("--rebuild", action="store_true", help="with --animate: full LBVH rebuild every frame instead of the refit (the round-1 behaviour, for comparison)")
     args = ap.parse_args()
 
     import numpy as np
@@ -93,7 +107,6 @@ def main():
 
     from gltf_renderer_amd import scenes, abi
     from gltf_renderer_amd.renderer import Renderer
-    from gltf_renderer_amd.sharding import TileExchange, reduce_frame
 
     t_setup = time.time()
     if args.config == "sponza":
@@ -104,6 +117,8 @@ def main():
         s = scenes.material_grid()
     elif args.config == "figure":
         s = scenes.skinned_figure()
+    elif args.config == "sponza_figure":
+        s = scenes.sponza_with_figure()
     else:
         s = scenes.test_scene(512, 256)
     if args.width and args.height:
@@ -115,107 +130,110 @@ def main():
     binding = None
     if args.animate:
         if not s.skins:
-            raise SystemExit("--animate needs a scene with a skinned mesh (--config figure)")
-        binding = scenes.SkinBinding(r, s, h, 0, use_mfma=1)      # every rank skins and rebuilds itself
+            raise SystemExit("--animate needs a scene with a skinned mesh (--config figure or sponza_figure)")
+        binding = scenes.SkinBinding(r, s, h, 0, use_mfma=1)      # every rank skins and refits itself
         binding.pose(0.0)
     r.build_accel()
     settings = s.settings
-    SPP_PER_GPU = 8                           # an offline renderer accumulates many samples: 8 per launch amortise the stage tails
-    spp = args.spp if args.spp > 0 else min(SPP_PER_GPU * (world if args.scaling == "weak" else 1), 64)
+    base_spp = args.spp if args.spp > 0 else SPP_PER_STEP
     if args.animate:
-        spp = 1                               # a playing animation resets accumulation every frame (Main.cpp:521-523)
-    r.set_samples_per_trace(spp)              # one launch carries the step's samples: a 1/N tile shard still fills the GPU
+        base_spp = 1                          # a playing animation resets accumulation every frame (Main.cpp:521-523)
     r.set_null_shadow_culling(args.cull_null_shadow)
     out = r.create_output(s.width, s.height)
     torch.cuda.synchronize()
-    accel_ms = r.stats().accel_ms
+    st_build = r.stats()
+    accel_ms = st_build.accel_ms
     t_setup = time.time() - t_setup
 
-    # The one exchange per frame (sharding.py): "gather" = every rank sends only its own tiles to rank 0 point to point over
-    # its direct xGMI link; "reduce" = RCCL reduce(sum) of the zeroed full-size image.  Both assemble the same bits.
-    exchange = {"mode": args.exchange if world > 1 else "none"}
-    xch = TileExchange(s.width, s.height, world, "cuda" if args.backend == "nccl" else "cpu") if world > 1 else None
+    # ---- the one exchange per step: libmipt.so's own RCCL exchange; the torch.distributed double only for gloo rehearsals
+    exchange_mode = args.exchange if world > 1 else "none"
+    xch = None
+    if world > 1 and args.backend == "nccl":
+        ids = [r.exchange_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)                # the host's transport for the 128-byte ncclUniqueId
+        r.exchange_create(rank, world, ids[0])
+    elif world > 1:
+        from gltf_renderer_amd.sharding import TileExchange
+        xch = TileExchange(s.width, s.height, world, "cpu")
 
-    def reduce_image(img):
-        if args.backend == "gloo":          # rehearsal path: gloo moves host tensors
+    def exchange(img):
+        if world == 1:
+            return
+        if xch is None:                     # product path: RCCL inside the library, on the launch stream, assembled in place on rank 0
+            r.exchange_frame(img, None, mode=abi.EXCHANGE_GATHER if exchange_mode == "gather" else abi.EXCHANGE_REDUCE, dst=0)
+        else:                               # rehearsal: gloo moves host tensors
             host = img.cpu()
-            if exchange["mode"] == "gather":
-                xch.gather_frame(host, rank)
-            else:
-                reduce_frame(host, world)
+            res = xch.gather_frame(host, rank) if exchange_mode == "gather" else xch.reduce_frame(host, rank)
             if rank == 0:
-                img.copy_(host)
-        elif exchange["mode"] == "gather":
-            xch.gather_frame(img, rank)
-        else:
-            reduce_frame(img, world)        # one RCCL reduce(sum) of the accumulation buffer over xGMI
-
-    def clear_for_exchange():
-        if exchange["mode"] == "reduce":    # the sum needs zeros outside this rank's tiles; the gather does not read them
-            out.zero_()
+                img.copy_(res)
 
     def animate(frame):
-        if binding is not None:           # Main.cpp:521-523: a playing animation resets accumulation every frame
+        if binding is not None:             # Main.cpp:521-523: a playing animation resets accumulation every frame
             binding.pose((frame % 60) / 30.0)
-            r.build_accel()
+            if args.rebuild:
+                r.request_rebuild()
+            r.build_accel()                 # refit (UpdateDynamicBlas), or the full rebuild with --rebuild
             settings.reset = 1
-
-    def step(frame):
-        animate(frame)
-        if world > 1:
-            clear_for_exchange()
-            settings.reset = 1          # each step is a fresh 1-spp frame when sharded (the exchange assembles disjoint tiles)
-        p = s.execute_params(frame=frame * spp, tile_rank=rank, tile_rank_count=world, env_handle=h["env"])
-        r.trace(settings, p, out)
-        if world > 1:
-            reduce_image(out)
 
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world > 1 and exchange["mode"] == "gather":
-        try:                                  # probe once: a backend without gather falls back to the reduce on every rank alike
-            step(0)
-            torch.cuda.synchronize()
-        except Exception as e:               # noqa: BLE001
-            if rank == 0:
-                print("gather exchange unavailable (%s); using reduce" % e, file=sys.stderr)
-            exchange["mode"] = "reduce"
-    for f in range(args.warmup):
-        step(f)
-    sync_all()
-    r.reset_stats()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    sync_all()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        frame = args.warmup + k
-        animate(frame)
-        if world > 1:
-            clear_for_exchange()
-            settings.reset = 1
-        p = s.execute_params(frame=frame * spp, tile_rank=rank, tile_rank_count=world, env_handle=h["env"])
-        ev[k][0].record()
-        r.trace(settings, p, out)
-        ev[k][1].record()
-        if world > 1:
-            reduce_image(out)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    st = r.stats()
-    kernel_ms = [a.elapsed_time(b) for a, b in ev]
-    rays_local = int(st.rays)
-
     stat_dev = "cuda" if args.backend == "nccl" else "cpu"
-    el = torch.tensor([elapsed], dtype=torch.float64, device=stat_dev)
-    ry = torch.tensor([rays_local], dtype=torch.float64, device=stat_dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(ry, op=dist.ReduceOp.SUM)
-    elapsed = float(el.item())
-    rays_total = float(ry.item())
+
+    def timed_run(spp, first_frame):
+        """warmup + K timed steps at `spp` samples per step.  Returns (elapsed max over ranks, rays of all ranks, per-step kernel ms)."""
+        r.set_samples_per_trace(spp)
+        state = {"acc": 0}
+        settings.reset = 1
+
+        def step(frame):
+            animate(frame)
+            if state["acc"] + spp > settings.max_accumulated_frames:     # never let a step become a no-op (Pathtracer.cpp:273)
+                settings.reset = 1
+            if settings.reset:
+                state["acc"] = 0
+            p = s.execute_params(frame=frame * spp, tile_rank=rank, tile_rank_count=world, env_handle=h["env"])
+            r.trace(settings, p, out)
+            settings.reset = 0
+            state["acc"] += spp
+            exchange(out)
+
+        for f in range(args.warmup):
+            step(first_frame + f)
+        sync_all()
+        r.reset_stats()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        sync_all()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            frame = first_frame + args.warmup + k
+            animate(frame)
+            if state["acc"] + spp > settings.max_accumulated_frames:
+                settings.reset = 1
+            if settings.reset:
+                state["acc"] = 0
+            p = s.execute_params(frame=frame * spp, tile_rank=rank, tile_rank_count=world, env_handle=h["env"])
+            ev[k][0].record()
+            r.trace(settings, p, out)
+            ev[k][1].record()
+            settings.reset = 0
+            state["acc"] += spp
+            exchange(out)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        st = r.stats()
+        el = torch.tensor([elapsed], dtype=torch.float64, device=stat_dev)
+        ry = torch.tensor([float(st.rays)], dtype=torch.float64, device=stat_dev)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            dist.all_reduce(ry, op=dist.ReduceOp.SUM)
+        return float(el.item()), float(ry.item()), [a.elapsed_time(b) for a, b in ev]
+
+    # ---- headline: the 8-spp step (split N ways when sharded: strong scaling)
+    elapsed, rays_total, kernel_ms = timed_run(base_spp, 0)
+    spp = base_spp
 
     result = None
     if rank == 0:
@@ -224,116 +242,198 @@ def main():
             "metric": "Mrays/sec + ms/frame @1920x1080, 8-bounce, 1/2/4/8 MI355X",
             "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1000.0, 4), "higher_is_better": True,
-            "scaling": "weak" if (args.scaling == "weak" and args.spp <= 0) else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %dx%d %dspp/step, max_bounces %d (limit %d), min_bounces %d, RR %.1f-%.1f, %d triangles / %d instances / %d textures / %d lights, env-map MIS, flags 0x%x"
                        % (s.name, s.width, s.height, spp, settings.max_bounces, s.bounce_limit, settings.min_bounces,
                           settings.min_russian_roulette_continue_prob, settings.max_russian_roulette_continue_prob, s.triangles,
                           len(s.instances), len(s.textures), len(s.lights), settings.flags),
-                       "parallelism": ("tile-shard x%d + 1 RCCL %s/frame" % (world, "tile gather to rank 0 (point to point)" if exchange["mode"] == "gather" else "reduce(sum)"))
+                       "parallelism": ("tile-shard x%d + 1 RCCL exchange/step in libmipt.so (%s)" % (world, "own-tile gather to rank 0, point to point" if exchange_mode == "gather" else "ncclReduce of the zero-masked copy"))
                                       if world > 1 else "single GPU",
                        "null_shadow_culling": bool(args.cull_null_shadow),
                        "samples_per_step": spp, "ms_per_1spp_frame": round(elapsed / args.steps / spp * 1000.0, 4),
-                       "rays_per_frame": round(rays_total / args.steps / spp, 1), "bvh_build_ms": round(accel_ms, 3), "scene_setup_s": round(t_setup, 1)},
+                       "rays_per_frame": round(rays_total / args.steps / spp, 1), "bvh_build_ms": round(accel_ms, 3),
+                       "bvh_stack_need": int(st_build.bvh_stack_need), "scene_setup_s": round(t_setup, 1)},
         }
+        if world > 1:
+            result["scaling"] = "strong"          # N = 1 has no scaling mode: the key is omitted there
+            if args.backend != "nccl":
+                result["config"]["parallelism"] += " [REHEARSAL over gloo on %s: not an RCCL measurement]" % ("one GPU" if args.single_device else "the host")
 
-    # ---- latency of a single-sample launch (one reference frame), untimed, beside the batched throughput
-    if rank == 0 and world == 1 and spp > 1 and binding is None and not args.no_roofline:     # (--no-roofline = profiling runs: timed launches only)
+    # ---- N > 1: the weak-scaling variant of the same run (8 x N samples per step, per-GPU work fixed)
+    if world > 1 and not args.no_weak and not args.animate:
+        wspp = min(base_spp * world, 64)
+        w_elapsed, w_rays, _ = timed_run(wspp, 1000)
+        if rank == 0:
+            result["weak_scaling"] = {"scaling": "weak", "value": round(w_rays / w_elapsed / 1e6, 3), "unit": "Mrays/s", "samples_per_step": wspp,
+                                      "ms_per_step": round(w_elapsed / args.steps * 1000.0, 4), "ms_per_1spp_frame": round(w_elapsed / args.steps / wspp * 1000.0, 4)}
+        r.set_samples_per_trace(spp)
+
+    # ---- latency of a single-sample launch (one reference frame): median of >= 20 after 3 warm-ups
+    if rank == 0 and world == 1 and binding is None and not args.no_roofline:     # (--no-roofline = profiling runs: timed launches only)
         r.set_samples_per_trace(1)
-        lat = []
-        for k in range(6):
+        lat, rays1 = [], 0
+        settings.reset = 1
+        for k in range(3 + max(20, args.steps)):
+            if k == 3:
+                r.reset_stats()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             r.trace(settings, s.execute_params(frame=100000 + k, env_handle=h["env"]), out)
             b.record()
+            settings.reset = 0
             torch.cuda.synchronize()
-            lat.append(a.elapsed_time(b))
-        result["config"]["ms_single_sample_launch"] = round(sorted(lat[1:])[len(lat[1:]) // 2], 4)
+            if k >= 3:
+                lat.append(a.elapsed_time(b))
+        rays1 = r.stats().rays / len(lat)
+        result["config"]["ms_single_sample_launch"] = round(median(lat), 4)
+        result["config"]["mrays_single_sample_launch"] = round(rays1 / (median(lat) * 1e-3) / 1e6, 1)
+        result["config"]["single_sample_launches_timed"] = len(lat)
         r.set_samples_per_trace(spp)
 
-    # ---- config 5: skin / BVH rebuild / trace split, measured on an untimed synchronised replay of a few frames
+    # ---- dynamic path: skin / accel (refit or rebuild) / trace split, measured on an untimed synchronised replay of a few frames
     if rank == 0 and binding is not None:
         parts = {"skin_ms": [], "accel_ms": [], "trace_ms": []}
-        for k in range(min(args.steps, 8)):
+        for k in range(max(args.steps, 8)):
             animate(args.warmup + k)
             r.trace(settings, s.execute_params(frame=(args.warmup + k) * spp, tile_rank=rank, tile_rank_count=world, env_handle=h["env"]), out)
             torch.cuda.synchronize()
             st2 = r.stats()
             parts["skin_ms"].append(st2.skin_ms); parts["accel_ms"].append(st2.accel_ms); parts["trace_ms"].append(st2.trace_ms)
-        result["config"]["dynamic_ms"] = {k2: round(sum(v) / len(v), 4) for k2, v in parts.items()}
-        result["config"]["parallelism"] += "; skin (MFMA joint blend) + full LBVH rebuild + 1 spp trace per step"
+        result["config"]["dynamic_ms"] = {k2: round(median(v), 4) for k2, v in parts.items()}
+        st2 = r.stats()
+        result["config"]["dynamic_ms"]["accel"] = "full rebuild every frame (--rebuild)" if args.rebuild else "refit (UpdateDynamicBlas); full builds so far: %d, refits: %d" % (st2.accel_builds, st2.accel_refits)
+        result["config"]["dynamic_ms"]["first_build_ms"] = round(accel_ms, 4)
+        result["config"]["parallelism"] += "; skin (MFMA joint blend) + %s + 1 spp trace per step" % ("full LBVH rebuild" if args.rebuild else "BVH refit")
 
-    # ---- roofline: instrumented untimed replay of the same frames (rank 0, N = 1 only)
-    if rank == 0 and world == 1 and not args.no_roofline:
-        r.enable_counters(True)
+    # ---- roofline (rank 0, N = 1): stage times from an untimed replay with an event after every stage launch, then the same
+    # frames once more with the node / triangle / hit / tap counters on (the counting kernels are slower, so they are never timed)
+    if rank == 0 and world == 1 and not args.no_roofline and args.mode == "wavefront":
         settings2 = abi.PtSettings.from_buffer_copy(bytes(settings))
         out2 = r.create_output(s.width, s.height)
-        torch.cuda.synchronize()
-        r.reset_stats()
+        n = float(args.steps)
+        stage_ms = [0.0] * 5
+        r.enable_stage_timing(True)
+        settings2.reset = 1
         for k in range(args.steps):
             animate(args.warmup + k)
             if binding is not None:
                 settings2.reset = 1
-            p = s.execute_params(frame=(args.warmup + k) * spp, env_handle=h["env"])
-            r.trace(settings2, p, out2)
+            r.trace(settings2, s.execute_params(frame=(args.warmup + k) * spp, env_handle=h["env"]), out2)
+            settings2.reset = 0
+            q = r.stats()
+            for i in range(5):
+                stage_ms[i] += q.stage_ms[i] / n
+        r.enable_stage_timing(False)
+        r.enable_counters(True)
+        torch.cuda.synchronize()
+        r.reset_stats()
+        settings2.reset = 1
+        for k in range(args.steps):
+            animate(args.warmup + k)
+            if binding is not None:
+                settings2.reset = 1
+            r.trace(settings2, s.execute_params(frame=(args.warmup + k) * spp, env_handle=h["env"]), out2)
+            settings2.reset = 0
         c = r.stats()
         r.enable_counters(False)
-        n = float(args.steps)
         env_mis = bool(settings.flags & abi.FLAG_ENVIRONMENT_MIS) and bool(settings.flags & abi.FLAG_ENVIRONMENT_MAP)
-        # bytes/ray = N_node*node_size + N_tri*48 + [closest hits] S_hit + 32/R per pixel-sample.  Node size is
-        # 64 B (the quantised 4-wide node of this build; the survey's figure).
-        s_hit = 12 + 3 * (12 + 4 + 8) + 176 + 640            # indices + 3 vertices + instance row + material
-        alg = (c.nodes_visited * 64 + c.tris_tested * 48 + c.closest_hits * s_hit + c.texture_taps * 16
-               + (c.closest_hits * 40 * 4 if env_mis else 0) + (c.rays_primary + c.rays_bounce - c.closest_hits) * 64) / n + s.width * s.height * 32 * spp
-        mean_ms = sum(kernel_ms) / len(kernel_ms)
-        achieved = alg / (mean_ms * 1e-3) / 1e9
-        traffic = None
-        pj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pj) and args.config == "sponza" and not (args.width or args.height or args.animate) and args.mode == "wavefront":
+        # bytes/ray = N_node*64 + N_tri*48 + [closest hits] S_hit + [misses] 64 + 32/R per pixel-sample; S_hit = 12 (indices)
+        # + 72 (three vertices) + 176 (instance row) + 640 (material) + 16 per bilinear footprint + 160 (importance pyramid) with env MIS
+        nodes_c, tris_c = c.nodes_visited - c.nodes_visited_shadow, c.tris_tested - c.tris_tested_shadow
+        misses = c.rays_primary + c.rays_bounce - c.closest_hits
+        alg = {"trace": (nodes_c * 64 + tris_c * 48) / n,
+               "shadow": (c.nodes_visited_shadow * 64 + c.tris_tested_shadow * 48) / n,
+               "shade": (c.closest_hits * (12 + 72 + 176 + 640 + (160 if env_mis else 0)) + c.texture_taps * 16 + misses * 64) / n,
+               "generate+resolve": float(s.width * s.height * 32 * spp)}
+        # what the shade stage reads from tables it staged into LDS once per workgroup (material header + three slots, the 96-B
+        # instance row, the three coarsest level pairs of the importance pyramid) instead of fetching per hit
+        lds = c.closest_hits * (640 + 176 + (96 if env_mis else 0)) / n
+        ms = {"trace": stage_ms[1], "shade": stage_ms[2], "shadow": stage_ms[3], "generate+resolve": stage_ms[0] + stage_ms[4]}
+        roofs = {"trace": ("Infinity-Cache gather", 8600.0), "shadow": ("Infinity-Cache gather", 8600.0), "shade": ("HBM", 8000.0), "generate+resolve": ("HBM", 8000.0)}
+        pmc = {}
+        pmc_file = os.path.join("profiles", "r02_pmc_per_kernel.json")
+        if os.path.exists(os.path.join(ROOT, pmc_file)) and args.config == "sponza" and not (args.width or args.height or args.animate):
             try:
-                pm = json.load(open(pj))
-                if pm.get("samples_per_launch", 1) == spp:         # the PMC passes were taken at this batch size
-                    traffic = pm.get("hbm_bytes_per_launch")
+                pm = json.load(open(os.path.join(ROOT, pmc_file)))
+                if pm.get("samples_per_launch", 1) == spp:
+                    pmc = pm.get("stages", {})
             except Exception:
-                traffic = None
-        kname = ("pt_megakernel" if args.mode == "megakernel" else
-                 "pt_trace wavefront pipeline (k_wf_generate + (k_wf_trace, k_wf_shade, k_wf_shadow) x (max_bounces+1) + k_wf_resolve; "
-                 "one launch = one pt_trace = %d sample(s) per pixel)" % spp)
-        result["roofline"] = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                              "frac": round(achieved / 8000.0, 5), "traffic": traffic,
-                              "algorithmic_bytes_per_launch": round(alg), "kernel_ms_mean": round(mean_ms, 4),
-                              "nodes_per_ray": round(c.nodes_visited / max(c.rays, 1), 2), "tris_per_ray": round(c.tris_tested / max(c.rays, 1), 2),
-                              "rays_replay": int(c.rays),
-                              "note": "latency/issue-bound gather workload: BVH + geometry are L2 / Infinity-Cache resident, so measured HBM traffic is far below the algorithmic bytes (DESIGN.md)"}
+                pmc = {}
+        stages = {}
+        for k2 in alg:
+            gbs = alg[k2] / max(ms[k2], 1e-9) / 1e6
+            e = {"ms_per_launch": round(ms[k2], 4), "algorithmic_bytes_per_launch": round(alg[k2]), "achieved_GBps": round(gbs, 1),
+                 "roof": roofs[k2][0], "roof_GBps": roofs[k2][1], "frac_of_roof": round(gbs / roofs[k2][1], 4), "frac_of_hbm_peak": round(gbs / 8000.0, 4)}
+            if k2 == "shade":
+                e["lds_table_bytes_per_launch"] = round(lds)
+                e["fetched_bytes_per_launch"] = round(alg[k2] - lds)
+                e["fetched_GBps"] = round((alg[k2] - lds) / max(ms[k2], 1e-9) / 1e6, 1)
+            if k2 in pmc:
+                e["pmc"] = pmc[k2]
+            stages[k2] = e
+        dominant = max(("trace", "shade", "shadow"), key=lambda k2: ms[k2])
+        kernel_of = {"trace": "k_wf_trace", "shade": "k_wf_shade", "shadow": "k_wf_shadow"}
+        total_ms = sum(ms.values())
+        mean_ms = sum(kernel_ms) / len(kernel_ms)
+        total_alg = sum(alg.values())
+        d = stages[dominant]
+        traffic = pmc.get(dominant, {}).get("hbm_bytes_per_launch") if pmc else None
+        result["roofline"] = {
+            "bound": "hbm", "kernel": "%s (%.0f %% of a launch's GPU time; one launch = one pt_trace = %d sample(s) per pixel = %d launches of it)"
+                                      % (kernel_of[dominant], 100.0 * ms[dominant] / max(total_ms, 1e-9), spp, settings.max_bounces + 1),
+            "achieved": d["achieved_GBps"], "peak": 8000.0, "unit": "GB/s", "frac": round(d["achieved_GBps"] / 8000.0, 5),
+            "traffic": traffic, "traffic_source": (pmc_file + " (rocprofv3 --pmc passes of this command, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, summed over the kernel's launches of one pt_trace)") if traffic else None,
+            "limiter": "not HBM: dependent-gather latency and vector-memory issue (DESIGN.md section 4); the traversal stages read L2 / Infinity-Cache resident data",
+            "stages": stages,
+            "pipeline": {"kernel_ms_mean_timed": round(mean_ms, 4), "stage_ms_sum_replay": round(total_ms, 4), "algorithmic_bytes_per_launch": round(total_alg),
+                         "achieved_GBps": round(total_alg / (mean_ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(total_alg / (mean_ms * 1e-3) / 1e9 / 8000.0, 4),
+                         "pmc": pmc.get("pipeline")},
+            "nodes_per_ray": round(c.nodes_visited / max(c.rays, 1), 2), "tris_per_ray": round(c.tris_tested / max(c.rays, 1), 2), "rays_replay": int(c.rays),
+            "bytes_per_ray": round(total_alg * n / max(c.rays, 1), 1)}
 
-    # ---- CPU baseline: oracle (port) on a bounded sample of the same workload
+    # ---- CPU baseline: the oracle (port) on bounded samples of the same workload
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import pyoracle
         try:
             cores = len(os.sched_getaffinity(0))
         except Exception:
             cores = os.cpu_count() or 1
-        cores = max(1, min(cores, 16))       # the GPU box's CPU share for one GPU
         o = pyoracle.Oracle()
         n_env, cube, pyr = r.env_read(h["env"]) if h["env"] is not None else (None, None, None)
         ho = s.upload(o, env_raw=(n_env, cube, pyr) if n_env else None)
-        o.build_accel()
+        t1 = time.perf_counter(); o.build_accel(); build_wall = (time.perf_counter() - t1) * 1e3
         acc_ms, _ = o.timing()
         sw, sh = s.width, s.height
-        s.width, s.height = max(sw // 8, 16), max(sh // 8, 16)       # 240x135 sample of the 1080p frame: same camera, same scene
-        img = np.zeros((s.height, s.width, 4), np.float32)
-        o.counters()
-        t1 = time.perf_counter()
-        frames = 0
-        while time.perf_counter() - t1 < 10.0 and frames < 64:
-            o.trace(settings, s.execute_params(frame=args.warmup + frames, env_handle=ho["env"]), img, nthreads=cores)
-            frames += 1
-        dt = time.perf_counter() - t1
-        cc = o.counters()
-        s.width, s.height = sw, sh
-        result["cpu_baseline"] = {"value": round(cc["rays"] / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-                                  "sample": "%d frames of the same scene/camera/settings at %dx%d (1/64 of the pixels), oracle LBVH build %.0f ms (1 thread)"
-                                  % (frames, max(sw // 8, 16), max(sh // 8, 16), acc_ms)}
+
+        def cpu_trace(nthreads, budget_s, w, hgt):
+            s.width, s.height = w, hgt
+            img = np.zeros((hgt, w, 4), np.float32)
+            o.counters()
+            t1 = time.perf_counter()
+            frames = 0
+            while time.perf_counter() - t1 < budget_s and frames < 64:
+                o.trace(settings, s.execute_params(frame=args.warmup + frames, env_handle=ho["env"]), img, nthreads=nthreads)
+                frames += 1
+            dt = time.perf_counter() - t1
+            cc = o.counters()
+            s.width, s.height = sw, sh
+            return cc["rays"] / dt / 1e6, frames
+
+        v_all, f_all = cpu_trace(cores, 10.0, max(sw // 8, 16), max(sh // 8, 16))       # 240x135 sample of the 1080p frame: same camera, same scene
+        v_one, f_one = cpu_trace(1, 5.0, max(sw // 16, 16), max(sh // 16, 16))
+        legs = {"B1_tracer_1_thread_Mrays": round(v_one, 4), "B1_tracer_all_cores_Mrays": round(v_all, 4),
+                "B2_cpu_lbvh_build_1_thread_ms": round(acc_ms, 2), "B2_hip_lbvh_build_ms": round(accel_ms, 3), "B2_triangles": int(s.triangles),
+                "B2_note": "oracle LBVH (Morton, std::sort, Karras, bottom-up fit), single-threaded; the reference's own BVH is built by the D3D12 driver"}
+        # B2 refit + B4 skinning + B3 host work on the config-5 class scene (the dynamic path), GPU and CPU side by side
+        try:
+            legs.update(dynamic_legs(np, torch, scenes, abi, Renderer, pyoracle, local_rank))
+        except Exception as e:        # noqa: BLE001 -- a baseline leg must never take the headline down
+            legs["dynamic_legs_error"] = repr(e)
+        result["cpu_baseline"] = {"value": round(v_all, 4), "unit": "Mrays/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+                                  "value_1_thread": round(v_one, 4),
+                                  "sample": "all cores: %d frames of the same scene/camera/settings at %dx%d (1/64 of the pixels); 1 thread: %d frames at %dx%d"
+                                            % (f_all, max(sw // 8, 16), max(sh // 8, 16), f_one, max(sw // 16, 16), max(sh // 16, 16)),
+                                  "legs": legs}
 
     if rank == 0:
         if args.save_image:
@@ -344,6 +444,72 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def dynamic_legs(np, torch, scenes, abi, Renderer, pyoracle, device):
+    """BASELINE.md section 3, legs B2 (refit), B3, B4 on the config-5 class scene: CPU restatement and HIP path side by side."""
+    import tempfile
+    legs = {}
+    s = scenes.skinned_figure(256, 144)
+    nv = s.skins[0]["mesh"].num_vertices
+    # ---- B4: skinning.  CPU oracle (1 thread; Skin.cs.hlsl restated) vs k_skin / k_skin_mfma
+    o = pyoracle.Oracle(); ho = s.upload(o)
+    bo = scenes.SkinBinding(o, s, ho, 0, use_mfma=0)
+    bones = scenes.bones_for_pose(bo.skin, np.eye(4), scenes.skinned_figure_pose(0.4))
+    t0 = time.perf_counter(); reps = 0
+    while time.perf_counter() - t0 < 1.0:
+        o.skin_run(bo.params, bones); reps += 1
+    cpu_skin_ms = (time.perf_counter() - t0) / reps * 1e3
+    t0 = time.perf_counter(); o.build_accel(); cpu_build_ms = o.timing()[0]
+    o.close()
+    legs["B4_cpu_skin_1_thread_ms"] = round(cpu_skin_ms, 4)
+    legs["B4_cpu_skin_Mverts_per_s"] = round(nv / cpu_skin_ms / 1e3, 2)
+    r = Renderer(device=device); h = s.upload(r)
+    for mfma in (0, 1):
+        b = scenes.SkinBinding(r, s, h, 0, use_mfma=mfma)
+        ms = []
+        for k in range(12):
+            b.pose(0.1 * k)
+            torch.cuda.synchronize()
+            ms.append(r.stats().skin_ms)
+        legs["B4_hip_skin_%s_ms" % ("mfma" if mfma else "valu")] = round(median(ms[2:]), 4)
+    legs["B4_vertices"] = int(nv)
+    # ---- B2: refit vs full rebuild of the same dynamic scene, HIP; CPU LBVH build of it (the oracle has no refit: it rebuilds)
+    b.pose(0.0); r.build_accel()
+    refit, rebuild = [], []
+    for k in range(10):
+        b.pose(0.05 * k); r.build_accel(); torch.cuda.synchronize(); refit.append(r.stats().accel_ms)
+    for k in range(6):
+        b.pose(0.05 * k); r.request_rebuild(); r.build_accel(); torch.cuda.synchronize(); rebuild.append(r.stats().accel_ms)
+    legs["B2_dynamic_scene_triangles"] = int(s.triangles)
+    legs["B2_hip_refit_ms"] = round(median(refit[2:]), 4)
+    legs["B2_hip_rebuild_ms"] = round(median(rebuild[1:]), 4)
+    legs["B2_cpu_lbvh_build_dynamic_scene_ms"] = round(cpu_build_ms, 3)
+    r.close()
+    # ---- B3: the reference's per-frame host work restated (Gltf::Animate + CalculateGlobalTransforms, PerformSkinning's bone
+    # matrices, GatherLights, GatherMaterials, BuildTlas' instance walk: Gltf.cpp:977-1041, Renderer.cpp:399-500, Pathtracer.cpp:185-257),
+    # single thread as upstream, on the figure scene exported to .glb and loaded back by the C++ loader
+    from gltf_renderer_amd.gltf import GltfScene
+    from tests.scene_export import skinned_figure_to_builder
+    with tempfile.TemporaryDirectory() as tmp:
+        path = skinned_figure_to_builder(s).write_glb(os.path.join(tmp, "figure.glb"))
+        r = Renderer(device=device)
+        sc = GltfScene(path)
+        sc.upload(r)
+        host_us = []
+        for k in range(60):
+            t0 = time.perf_counter()
+            sc.animate(0, (k % 60) / 30.0)
+            sc.calculate_global_transforms(0)
+            sc.frame(r, 0)
+            host_us.append((time.perf_counter() - t0) * 1e6)
+            if k % 8 == 7:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        legs["B3_host_work_per_frame_us"] = round(median(host_us[5:]), 1)
+        legs["B3_note"] = "gs_animate + gs_calculate_global_transforms + gs_frame (C++ in libmipt.so, 1 thread, uploads staged asynchronously) on the %d-joint figure scene" % len(s.skins[0]["inverse_bind"])
+        sc.unload(r); sc.close(); r.close()
+    return legs
 
 
 if __name__ == "__main__":

@@ -381,7 +381,7 @@ public:
                 fc.spp = (uint32_t)batch;
                 if ((unsigned long long)fc.pixel_slots * fc.spp > 0x7fffffffull) return ctx->fail(PT_ERR_CAPACITY, "sample batch too large for this resolution");
                 const int stage_blocks = ctx->stage_blocks > 0 ? ctx->stage_blocks : stage_blocks_for((size_t)fc.pixel_slots * fc.spp);
-                size_t need = wavefront_workspace_bytes(fc.pixel_slots * fc.spp, stage_blocks);
+                size_t need = wavefront_workspace_bytes(fc, stage_blocks);
                 if (need > ctx->workspace_cap) {
                     HIPOK(hipStreamSynchronize(ctx->stream));
                     hipFree(ctx->d_workspace); ctx->d_workspace = nullptr; ctx->workspace_cap = 0;
@@ -934,7 +934,7 @@ int pt_get_stats(pt_ctx* ctx, pt_stats* out) {
     memset(out, 0, sizeof(*out));
     out->rays_primary = c.rays_primary; out->rays_bounce = c.rays_bounce; out->rays_shadow = c.rays_shadow;
     out->rays = c.rays_primary + c.rays_bounce + c.rays_shadow;
-    out->nodes_visited = c.nodes; out->tris_tested = c.tris; out->closest_hits = c.hits; out->texture_taps = c.taps;
+    out->nodes_visited = c.nodes + c.nodes_shadow; out->tris_tested = c.tris + c.tris_shadow; out->closest_hits = c.hits; out->texture_taps = c.taps;
     out->nodes_visited_shadow = c.nodes_shadow; out->tris_tested_shadow = c.tris_shadow;
     if (ctx->have_trace) hipEventElapsedTime(&out->trace_ms, ctx->ev_trace[0], ctx->ev_trace[1]);
     if (ctx->have_accel) hipEventElapsedTime(&out->accel_ms, ctx->ev_accel[0], ctx->ev_accel[1]);

@@ -90,7 +90,7 @@ struct StageTimers {
     size_t used = 0;                     // launches recorded by the last pt_trace
 };
 void launch_megakernel(const SceneRec& sc, const FrameConstants& fc, float4* output, Counters* counters, bool count, hipStream_t stream);
-size_t wavefront_workspace_bytes(uint32_t slots, int stage_blocks);
+size_t wavefront_workspace_bytes(const FrameConstants& fc, int stage_blocks);
 hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4* output, Counters* counters, bool count, void* workspace,
                             int stage_blocks, StageTimers* timers, hipStream_t stream);
 

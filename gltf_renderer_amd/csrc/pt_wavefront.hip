@@ -56,6 +56,7 @@ struct WfBuffers {
     uint32_t capacity;    // slots
     uint32_t seg_cap;     // entries per closest-queue segment
     uint32_t blocks_per_shard;
+    uint32_t gen_region_tiles, gen_rounds;     // k_wf_generate: tiles per XCD band, workgroup-rounds to cover a band's (tile, sample) pairs
 };
 
 // wave64 ballot compaction into a shard counter: lanes with `pred` get consecutive indices; one atomic per wave.
@@ -81,20 +82,53 @@ PT_DEV ShardView shard_view(const WfBuffers& wf) {
     return v;
 }
 
+// Which pixel tiles a workgroup generates.  Workgroups are dispatched to the eight XCDs round-robin (XCD = blockIdx % 8), every later
+// stage launch has the same grid, and shard s = blockIdx % kShards is only ever touched by workgroups with blockIdx % 8 == s % 8:
+// a path lives its whole life on ONE XCD.  Each XCD has its own 4-MiB L2, and the scene (BVH + packets, tens of MB) fits none of
+// them; so each XCD is given a CONTIGUOUS range of this rank's tiles (a band of the screen) -- its primary rays, their shadow rays
+// and most first bounces then walk one part of the scene, and its L2 holds that part instead of a 1/8 sample of everything.
+// Within the band, consecutive workgroups of the XCD take consecutive (tile, sample) pairs.  Slots keep their meaning
+// (slot = sample * pixel_slots + tile * 256 + lane), only the workgroup that generates a slot changes: images are bit-identical.
+constexpr uint32_t kXcds = 8;
+#ifndef PT_GEN_XCD_BANDS
+#define PT_GEN_XCD_BANDS 1
+#endif
 __global__ __launch_bounds__(kBlock) void k_wf_generate(FrameConstants fc, WfBuffers wf, Counters* __restrict__ counters) {
     const ShardView sv = shard_view(wf);
-    const uint32_t total = gridDim.x * kBlock;
-    const uint32_t rounds = (wf.capacity + total - 1) / total;
+    const uint32_t per_xcd = gridDim.x / kXcds;                       // the grid is a multiple of kShards, kShards of kXcds
+    const uint32_t xcd = blockIdx.x % kXcds, member = blockIdx.x / kXcds;
+    uint32_t first_tile = xcd * wf.gen_region_tiles;
+    uint32_t n_tiles = first_tile < fc.my_tiles ? min(wf.gen_region_tiles, fc.my_tiles - first_tile) : 0u;
+#if PT_GEN_XCD_BANDS == 2
+    // column bands (whole frames only; a tile shard of a frame keeps the ranges of its own tile list): XCD x owns the tile columns
+    // [c0, c1) over all rows -- every band holds sky, walls and floor alike, so the eight XCDs finish together
+    const bool columns = fc.tile_rank_count == 1;
+    const uint32_t c0 = xcd * fc.tiles_x / kXcds, band_w = (xcd + 1u) * fc.tiles_x / kXcds - c0;
+    if (columns) n_tiles = band_w * fc.tiles_y;
+#endif
     unsigned n_primary = 0;
-    for (uint32_t rnd = 0; rnd < rounds; rnd++) {
-        // a workgroup-round is 256 consecutive slots = one 16x16 tile: primary rays stay coherent per wave (8x8 quadrant)
+    for (uint32_t rnd = 0; rnd < wf.gen_rounds; rnd++) {
+        // a workgroup-round is one 16x16 tile of one sample: primary rays stay coherent per wave (8x8 quadrant)
+#if PT_GEN_XCD_BANDS
+        const uint32_t q = rnd * per_xcd + member;
+        const uint32_t tile_in_region = q / fc.spp, sample = q - tile_in_region * fc.spp;
+        uint32_t tile = first_tile + tile_in_region;
+#if PT_GEN_XCD_BANDS == 2
+        if (columns) { const uint32_t brow = band_w ? tile_in_region / band_w : 0u; tile = brow * fc.tiles_x + c0 + (tile_in_region - brow * band_w); }
+#endif
+        const uint32_t slot = sample * fc.pixel_slots + tile * kBlock + threadIdx.x;
+        uint32_t px = 0, py = 0;
+        const bool valid = tile_in_region < n_tiles && slot_pixel(fc, slot, px, py);
+#else       // A/B: tiles dealt round-robin over all workgroups (every XCD sees the whole screen); rounds are sized for either
         const uint32_t slot = (rnd * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+        const uint32_t sample = slot_sample(fc, slot);
         uint32_t px = 0, py = 0;
         const bool valid = slot < wf.capacity && slot_pixel(fc, slot, px, py);
+#endif
         int rc = 0;
         Ray ray;
         ray.o = v3(0); ray.d = v3(0, 0, 1); ray.tmin = 0; ray.tmax = 0;
-        if (valid) ray = camera_ray(fc, sample_seed(fc, slot_sample(fc, slot)), px, py, rc);
+        if (valid) ray = camera_ray(fc, sample_seed(fc, sample), px, py, rc);
         const uint32_t idx = queue_push(wf.cnt[0] + sv.shard * kCounterStride, valid);
         if (valid) {
             const size_t e = (size_t)sv.shard * wf.seg_cap + idx;
@@ -351,25 +385,39 @@ static uint32_t blocks_per_shard_for(int stage_blocks) {
     uint32_t b = (uint32_t)(stage_blocks > 0 ? stage_blocks : 1536) / kShards;
     return b < 1 ? 1 : b;
 }
-static uint32_t seg_cap_for(uint32_t slots, uint32_t blocks_per_shard) {
-    // generate round r gives shard s the slots of workgroups {s, s + kShards, ...}: blocks_per_shard * 256 per round
-    const uint32_t total = kShards * blocks_per_shard * kBlock;
-    const uint32_t rounds = (slots + total - 1) / total;
-    return rounds * blocks_per_shard * kBlock;
+// k_wf_generate: every XCD covers its band of tiles x spp samples with its kShards * blocks_per_shard / 8 workgroups
+static uint32_t gen_region_tiles_for(const FrameConstants& fc) {
+#if PT_GEN_XCD_BANDS == 2
+    if (fc.tile_rank_count == 1) return ((fc.tiles_x + kXcds - 1) / kXcds) * fc.tiles_y;      // the widest column band
+#endif
+    return (fc.my_tiles + kXcds - 1) / kXcds;
+}
+static uint32_t gen_rounds_for(const FrameConstants& fc, uint32_t blocks_per_shard) {
+    const uint32_t per_xcd = kShards * blocks_per_shard / kXcds;
+    const uint32_t pairs = gen_region_tiles_for(fc) * fc.spp;
+    return (pairs + per_xcd - 1) / per_xcd;
+}
+static uint32_t seg_cap_for(const FrameConstants& fc, uint32_t blocks_per_shard) {
+    // a generate round gives shard s one tile from each of its blocks_per_shard workgroups {s, s + kShards, ...}
+    return gen_rounds_for(fc, blocks_per_shard) * blocks_per_shard * kBlock;
 }
 
-size_t wavefront_workspace_bytes(uint32_t slots, int stage_blocks) {
+size_t wavefront_workspace_bytes(const FrameConstants& fc, int stage_blocks) {
     const uint32_t bps = blocks_per_shard_for(stage_blocks);
-    const size_t q = (size_t)kShards * seg_cap_for(slots, bps);
-    return (size_t)slots * (5 * 16 + 4) + q * (4 * 16 + 16 + 2 * 2 * 16) + 5 * kShards * kCounterStride * 4 + 32 * 256;
+    const size_t slots = (size_t)fc.my_tiles * kBlock * fc.spp;
+    const size_t q = (size_t)kShards * seg_cap_for(fc, bps);
+    return slots * (5 * 16 + 4) + q * (4 * 16 + 16 + 2 * 2 * 16) + 5 * kShards * kCounterStride * 4 + 32 * 256;
 }
 
-static WfBuffers carve(void* base, uint32_t slots, int stage_blocks) {
+static WfBuffers carve(void* base, const FrameConstants& fc, int stage_blocks) {
+    const uint32_t slots = fc.my_tiles * kBlock * fc.spp;
     WfBuffers wf;
     char* p = (char*)base;
     auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
     wf.blocks_per_shard = blocks_per_shard_for(stage_blocks);
-    wf.seg_cap = seg_cap_for(slots, wf.blocks_per_shard);
+    wf.seg_cap = seg_cap_for(fc, wf.blocks_per_shard);
+    wf.gen_region_tiles = gen_region_tiles_for(fc);
+    wf.gen_rounds = gen_rounds_for(fc, wf.blocks_per_shard);
     const size_t q = (size_t)kShards * wf.seg_cap;
     for (int k = 0; k < 5; k++) wf.cnt[k] = (uint32_t*)take((size_t)kShards * kCounterStride * 4);
     wf.L = (float4*)take((size_t)slots * 16);
@@ -409,7 +457,7 @@ hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4
         timers->used = k + 1;
     };
     const uint32_t slots = fc.my_tiles * kBlock * fc.spp;
-    WfBuffers wf = carve(workspace, slots, stage_blocks);
+    WfBuffers wf = carve(workspace, fc, stage_blocks);
     hipError_t e = hipMemsetAsync(wf.cnt[0], 0, (size_t)5 * kShards * kCounterStride * 4, stream);     // the five counter arrays are contiguous
     if (e) return e;
     const dim3 block(kBlock), full(fc.my_tiles), stage(kShards * wf.blocks_per_shard);

@@ -553,10 +553,9 @@ def skinned_figure_pose(t):
     return glob
 
 
-def skinned_figure(width=3840, height=2160, seed=5):
-    """BASELINE config 5 stand-in for CesiumMan: capsule-limbed figure (~4.7 k triangles / ~3.3 k
-    vertices), 19 joints, 4 weights per vertex, 2 s walk cycle, ground plane; 4K, 8 bounces."""
-    s = SceneData("config5_skinned_figure")
+def add_skinned_figure(s, transform=None, seed=5):
+    """The CesiumMan-class figure as ONE dynamic instance of scene `s` (+ its skin record in s.skins): capsule-limbed body,
+    ~4.7 k triangles / ~3.3 k vertices, 19 joints, 4 weights per vertex.  Returns the instance index."""
     bones = [(0, 1, 0.13), (1, 2, 0.15), (2, 3, 0.07), (3, 4, 0.11), (2, 5, 0.07), (5, 6, 0.055), (6, 7, 0.045), (2, 8, 0.07), (8, 9, 0.055),
              (9, 10, 0.045), (0, 11, 0.08), (11, 12, 0.075), (12, 13, 0.06), (13, 14, 0.045), (0, 15, 0.08), (15, 16, 0.075), (16, 17, 0.06), (17, 18, 0.045)]
     parts, joints, weights = [], [], []
@@ -574,14 +573,22 @@ def skinned_figure(width=3840, height=2160, seed=5):
     h = value_noise(rng, 512, 4, 4)
     t_base = s.add_texture(rgba(0.5 + 0.4 * h, 0.3 + 0.3 * h, 0.25 + 0.2 * h), True)
     m_fig = s.add_material(material(albedo=PtTextureSample(t_base), metalness_factor=0.0, roughness_factor=0.6))
-    m_floor = s.add_material(material(base_color_factor=(0.5, 0.5, 0.5, 1), metalness_factor=0.0, roughness_factor=0.8))
-    inst = s.add_mesh(fig, None, m_fig, dynamic=True)
-    s.add_mesh(meshgen.grid(16, 16, (-4, -4, 0), (8, 0, 0), (0, 8, 0)), None, m_floor)
+    inst = s.add_mesh(fig, transform, m_fig, dynamic=True)
     inv_bind = [np.linalg.inv(camera.translate(JOINT_REST[j])) for j in range(19)]
     d = s.instances[inst]
     jw = s.add_buffer(meshgen.pack_joint_weight(fig.joints, fig.weights), abi.FORMAT_JOINT_WEIGHT)
     s.skins.append({"instance": inst, "mesh": fig, "joint_weight": jw, "inverse_bind": inv_bind,
                     "input_position": d.gpu.position_descriptor, "input_tangent_space": d.gpu.tangent_space_descriptor})
+    return inst
+
+
+def skinned_figure(width=3840, height=2160, seed=5):
+    """BASELINE config 5 stand-in for CesiumMan: capsule-limbed figure (~4.7 k triangles / ~3.3 k
+    vertices), 19 joints, 4 weights per vertex, 2 s walk cycle, ground plane; 4K, 8 bounces."""
+    s = SceneData("config5_skinned_figure")
+    add_skinned_figure(s, None, seed)
+    m_floor = s.add_material(material(base_color_factor=(0.5, 0.5, 0.5, 1), metalness_factor=0.0, roughness_factor=0.8))
+    s.add_mesh(meshgen.grid(16, 16, (-4, -4, 0), (8, 0, 0), (0, 8, 0)), None, m_floor)
     s.add_light(abi.LIGHT_POINT, position=(1.5, -2.0, 3.0), intensity=30.0)
     s.add_light(abi.LIGHT_DIRECTIONAL, direction=(-0.3, 0.4, -0.85), intensity=2.5)
     s.env_image = sky_image(1024, 512, 5.0e3)
@@ -591,6 +598,15 @@ def skinned_figure(width=3840, height=2160, seed=5):
     st.min_bounces, st.max_bounces = 2, 8
     s.settings = st
     s.bounce_limit = 8
+    return s
+
+
+def sponza_with_figure(width=1920, height=1080, tex=1024):
+    """A Sponza-class static background (~257 k triangles) with ONE animated character standing in the atrium: the case the
+    reference's per-frame flow is made for -- static BLASes kept, the dynamic BLAS refitted, the TLAS rebuilt (Pathtracer.cpp:138-257)."""
+    s = sponza_class(width, height, tex)
+    s.name = "sponza_class_with_skinned_figure"
+    add_skinned_figure(s, camera.trs((-6.5, -0.4, 0.0), scale=(1.6, 1.6, 1.6)))
     return s
 
 

@@ -20,7 +20,7 @@ def _worker(rank, world, port, tmp):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gltf_renderer_amd import abi, scenes
-    from gltf_renderer_amd.sharding import my_tile_count, reduce_frame
+    from gltf_renderer_amd.sharding import my_tile_count
     from oracle import pyoracle
     s = scenes.test_scene(40, 16)
     st = abi.PtSettings.from_buffer_copy(bytes(s.settings)); st.flags &= ~abi.FLAG_ACCUMULATE
@@ -32,16 +32,33 @@ def _worker(rank, world, port, tmp):
     # the point-to-point form of the exchange on a copy whose foreign pixels hold garbage (it must not read them) ...
     from gltf_renderer_amd.sharding import TileExchange
     g = torch.from_numpy(np.where(img[..., 3:4] != 0, img, np.float32(123.0)).astype(np.float32))
-    TileExchange(s.width, s.height, world, "cpu").gather_frame(g, rank)
+    xch = TileExchange(s.width, s.height, world, "cpu")
+    xch.gather_frame(g, rank)
     if rank == 0:
         np.save(os.path.join(tmp, "gathered.npy"), g.numpy())
-    # ... and the reduce(sum) form
-    reduce_frame(t, world)
+    # ... and the reduce(sum) form, on a zero-masked copy: the rank's own image is not touched
+    g2 = torch.from_numpy(np.where(img[..., 3:4] != 0, img, np.float32(np.nan)).astype(np.float32))
+    before = g2.clone()
+    red = xch.reduce_frame(g2, rank)
+    assert torch.equal(torch.nan_to_num(g2, nan=7.0), torch.nan_to_num(before, nan=7.0))
     counts = torch.tensor([touched, my_tile_count(s.width, s.height, rank, world)])
     dist.all_reduce(counts)
     if rank == 0:
-        np.save(os.path.join(tmp, "sharded.npy"), t.numpy())
+        np.save(os.path.join(tmp, "sharded.npy"), red.numpy())
         np.save(os.path.join(tmp, "counts.npy"), counts.numpy())
+    # ---- accumulation across frames composes with both exchanges (each rank's accumulation image stays private): three
+    # accumulated frames, one exchange after each, every assembled frame must equal the 1-rank running mean
+    st2 = abi.PtSettings.from_buffer_copy(bytes(s.settings)); st2.reset = 1
+    acc = np.zeros((s.height, s.width, 4), np.float32)
+    for f in range(3):
+        o.trace(st2, s.execute_params(frame=10 + f, env_handle=h["env"], tile_rank=rank, tile_rank_count=world), acc, nthreads=1)
+        st2.reset = 0
+        a_t = torch.from_numpy(acc)
+        frame_g = xch.gather_frame(a_t, rank, out=torch.empty_like(a_t) if rank == 0 else None)
+        frame_r = xch.reduce_frame(a_t, rank)
+        if rank == 0:
+            np.save(os.path.join(tmp, "acc_gather_%d.npy" % f), frame_g.numpy())
+            np.save(os.path.join(tmp, "acc_reduce_%d.npy" % f), frame_r.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -60,6 +77,15 @@ def test_two_rank_tile_sharding_equals_single_rank(tmp_path, oracle_lib):
     assert np.array_equal(np.load(tmp_path / "gathered.npy"), full)
     counts = np.load(tmp_path / "counts.npy")
     assert counts[0] == 40 * 40 and counts[1] == 9          # every pixel rendered exactly once; 3x3 tiles
+    # accumulate + exchange over three frames == the 1-rank running mean after each frame (an in-place reduce of the
+    # accumulation target double-counted the other ranks' tiles from the second frame on)
+    st2 = abi.PtSettings.from_buffer_copy(bytes(s.settings)); st2.reset = 1
+    acc = np.zeros((s.height, s.width, 4), np.float32)
+    for f in range(3):
+        o.trace(st2, s.execute_params(frame=10 + f, env_handle=h["env"]), acc, nthreads=1)
+        st2.reset = 0
+        assert np.array_equal(np.load(tmp_path / ("acc_gather_%d.npy" % f)), acc), f
+        assert np.array_equal(np.load(tmp_path / ("acc_reduce_%d.npy" % f)), acc), f
 
 
 def test_tile_partition_is_exact():

@@ -23,6 +23,14 @@ def is_pt(name):
 
 summary = {"tag": tag}
 lines = []
+_fp = os.path.join(out_dir, "bench_trace.log")
+if os.path.exists(_fp):
+    _last = [l for l in open(_fp).read().splitlines() if l.startswith("{")]
+    if _last:
+        try:
+            summary["bench"] = json.loads(_last[-1])
+        except Exception:
+            pass
 per = defaultdict(list)
 for f in find("trace/**/*kernel_trace.csv"):
     for row in csv.DictReader(open(f)):
@@ -75,6 +83,53 @@ if "TCC_HIT_sum" in p and "TCC_MISS_sum" in p:
     hr = p["TCC_HIT_sum"] / max(p["TCC_HIT_sum"] + p["TCC_MISS_sum"], 1)
     summary["l2_hit_rate"] = hr
     lines.append("L2 hit rate (path-tracing kernels): %.4f" % hr)
+
+# ---- per-kernel PMC split (FETCH / WRITE / TCC hit and miss per stage, so every fraction of bench.py's roofline
+# object can be recomputed from profiles/ alone).  Stage = the kernel family; per launch = per pt_trace = per frame of the run.
+def stage_of(name):
+    for key, st in (("k_wf_trace", "trace"), ("k_wf_shadow", "shadow"), ("k_wf_shade", "shade"), ("k_wf_generate", "generate+resolve"), ("k_wf_resolve", "generate+resolve"),
+                    ("k_wf_tail", "tail"), ("pt_megakernel", "megakernel")):
+        if key in name:
+            return st
+    return None
+
+
+per_stage = defaultdict(lambda: defaultdict(float))
+for sub in ("pmc_fetch", "pmc_write", "pmc_l2"):
+    for f in find(sub + "/**/*counter_collection.csv"):
+        for row in csv.DictReader(open(f)):
+            st = stage_of(row.get("Kernel_Name", ""))
+            if st:
+                per_stage[st][row["Counter_Name"]] += float(row["Counter_Value"]) / max(pmc_frames, 1)
+stage_ms = defaultdict(float)
+for name, v in per.items():
+    st = stage_of(name)
+    if st:
+        stage_ms[st] += sum(d[0] for d in v) / 1e6 / max(trace_frames, 1)
+stages = {}
+lines.append("per-stage PMC, per launch (= per pt_trace): stage | ms | FETCH_SIZE KB | WRITE_SIZE KB | HBM bytes raw | HBM bytes (FETCH x2) | HBM GB/s (x2) | TCC hit rate")
+tot_c = defaultdict(float)
+for st, cs in sorted(per_stage.items()):
+    fe, wr, hit, miss = cs.get("FETCH_SIZE", 0.0), cs.get("WRITE_SIZE", 0.0), cs.get("TCC_HIT_sum", 0.0), cs.get("TCC_MISS_sum", 0.0)
+    for k, v in cs.items():
+        tot_c[k] += v
+    raw, corr = (fe + wr) * 1024.0, (2.0 * fe + wr) * 1024.0
+    ms = stage_ms.get(st, 0.0)
+    stages[st] = {"kernel_ms_per_launch": ms, "FETCH_SIZE_KB": fe, "WRITE_SIZE_KB": wr, "TCC_HIT_sum": hit, "TCC_MISS_sum": miss,
+                  "hbm_bytes_per_launch_raw": raw, "hbm_bytes_per_launch": corr, "hbm_GBps": corr / max(ms, 1e-9) / 1e6,
+                  "l2_hit_rate": hit / max(hit + miss, 1.0), "l2_requests_per_launch": hit + miss}
+    lines.append("%-18s %9.3f %14.5g %14.5g %14.5g %14.5g %10.1f %8.4f" % (st, ms, fe, wr, raw, corr, corr / max(ms, 1e-9) / 1e6, hit / max(hit + miss, 1.0)))
+if stages:
+    fe, wr, hit, miss = tot_c.get("FETCH_SIZE", 0.0), tot_c.get("WRITE_SIZE", 0.0), tot_c.get("TCC_HIT_sum", 0.0), tot_c.get("TCC_MISS_sum", 0.0)
+    ms = sum(stage_ms.values())
+    stages["pipeline"] = {"kernel_ms_per_launch": ms, "hbm_bytes_per_launch_raw": (fe + wr) * 1024.0, "hbm_bytes_per_launch": (2 * fe + wr) * 1024.0,
+                          "hbm_GBps": (2 * fe + wr) * 1024.0 / max(ms, 1e-9) / 1e6, "l2_hit_rate": hit / max(hit + miss, 1.0)}
+    spp = (summary.get("bench") or {}).get("config", {}).get("samples_per_step")
+    pk = {"source": "tools/profile_gpu.sh %s: rocprofv3 --kernel-trace pass + separate --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_HIT_sum TCC_MISS_sum passes of the same bench.py command; values per launch (= per pt_trace), summed over the launches of each kernel family" % tag,
+          "correction": "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: gfx950 reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md); our scattered 16-B gathers are an uncalibrated pattern, so the raw figure is kept beside it",
+          "samples_per_launch": spp, "stages": stages}
+    summary["pmc_per_kernel"] = pk
+
 fp = os.path.join(out_dir, "bench_trace.log")
 if os.path.exists(fp):
     last = [l for l in open(fp).read().splitlines() if l.startswith("{")]
@@ -84,6 +139,10 @@ if os.path.exists(fp):
             summary["bench"] = json.loads(last[-1])
         except Exception:
             pass
+if "pmc_per_kernel" in summary:
+    if summary["pmc_per_kernel"].get("samples_per_launch") is None:
+        summary["pmc_per_kernel"]["samples_per_launch"] = (summary.get("bench") or {}).get("config", {}).get("samples_per_step")
+    json.dump(summary["pmc_per_kernel"], open(os.path.join(out_dir, "pmc_per_kernel.json"), "w"), indent=1)
 open(os.path.join(out_dir, "summary.txt"), "w").write("\n".join(lines) + "\n")
 json.dump(summary, open(os.path.join(out_dir, "summary.json"), "w"), indent=1)
 print("\n".join(lines))
