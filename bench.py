@@ -339,17 +339,19 @@ def main():
         env_mis = bool(settings.flags & abi.FLAG_ENVIRONMENT_MIS) and bool(settings.flags & abi.FLAG_ENVIRONMENT_MAP)
         # bytes/ray = N_node*64 + N_tri*48 + [closest hits] S_hit + [misses] 64 + 32/R per pixel-sample; S_hit = 12 (indices)
         # + 72 (three vertices) + 176 (instance row) + 640 (material) + 16 per bilinear footprint + 160 (importance pyramid) with env MIS
-        nodes_c, tris_c = c.nodes_visited - c.nodes_visited_shadow, c.tris_tested - c.tris_tested_shadow
         misses = c.rays_primary + c.rays_bounce - c.closest_hits
-        alg = {"trace": (nodes_c * 64 + tris_c * 48) / n,
-               "shadow": (c.nodes_visited_shadow * 64 + c.tris_tested_shadow * 48) / n,
+        # traversal = k_wf_trace (primary rays) + k_wf_traverse (the shadow rays of a bounce and the closest-hit rays of the next,
+        # fused in one launch) + the last k_wf_shadow; the counters still tell the two ray kinds apart
+        alg = {"traversal": (c.nodes_visited * 64 + c.tris_tested * 48) / n,
                "shade": (c.closest_hits * (12 + 72 + 176 + 640 + (160 if env_mis else 0)) + c.texture_taps * 16 + misses * 64) / n,
                "generate+resolve": float(s.width * s.height * 32 * spp)}
+        split = {"closest_hit_rays": {"rays": (c.rays_primary + c.rays_bounce) / n, "nodes": (c.nodes_visited - c.nodes_visited_shadow) / n, "tris": (c.tris_tested - c.tris_tested_shadow) / n},
+                 "shadow_rays": {"rays": c.rays_shadow / n, "nodes": c.nodes_visited_shadow / n, "tris": c.tris_tested_shadow / n}}
         # what the shade stage reads from tables it staged into LDS once per workgroup (material header + three slots, the 96-B
         # instance row, the three coarsest level pairs of the importance pyramid) instead of fetching per hit
         lds = c.closest_hits * (640 + 176 + (96 if env_mis else 0)) / n
-        ms = {"trace": stage_ms[1], "shade": stage_ms[2], "shadow": stage_ms[3], "generate+resolve": stage_ms[0] + stage_ms[4]}
-        roofs = {"trace": ("Infinity-Cache gather", 8600.0), "shadow": ("Infinity-Cache gather", 8600.0), "shade": ("HBM", 8000.0), "generate+resolve": ("HBM", 8000.0)}
+        ms = {"traversal": stage_ms[1] + stage_ms[3], "shade": stage_ms[2], "generate+resolve": stage_ms[0] + stage_ms[4]}
+        roofs = {"traversal": ("Infinity-Cache gather (MI355X_MICROARCH.md: 8.6 TB/s; L2-resident gather 16.8-18.8 TB/s)", 8600.0), "shade": ("HBM", 8000.0), "generate+resolve": ("HBM", 8000.0)}
         pmc = {}
         pmc_file = os.path.join("profiles", "r02_pmc_per_kernel.json")
         if os.path.exists(os.path.join(ROOT, pmc_file)) and args.config == "sponza" and not (args.width or args.height or args.animate):
@@ -364,6 +366,8 @@ def main():
             gbs = alg[k2] / max(ms[k2], 1e-9) / 1e6
             e = {"ms_per_launch": round(ms[k2], 4), "algorithmic_bytes_per_launch": round(alg[k2]), "achieved_GBps": round(gbs, 1),
                  "roof": roofs[k2][0], "roof_GBps": roofs[k2][1], "frac_of_roof": round(gbs / roofs[k2][1], 4), "frac_of_hbm_peak": round(gbs / 8000.0, 4)}
+            if k2 == "traversal":
+                e["split"] = {k3: {k4: round(v4, 1) for k4, v4 in v3.items()} for k3, v3 in split.items()}
             if k2 == "shade":
                 e["lds_table_bytes_per_launch"] = round(lds)
                 e["fetched_bytes_per_launch"] = round(alg[k2] - lds)
@@ -371,8 +375,8 @@ def main():
             if k2 in pmc:
                 e["pmc"] = pmc[k2]
             stages[k2] = e
-        dominant = max(("trace", "shade", "shadow"), key=lambda k2: ms[k2])
-        kernel_of = {"trace": "k_wf_trace", "shade": "k_wf_shade", "shadow": "k_wf_shadow"}
+        dominant = "shade"      # the single kernel with the largest share of a launch (the traversal figure sums two kernels)
+        kernel_of = {"shade": "k_wf_shade"}
         total_ms = sum(ms.values())
         mean_ms = sum(kernel_ms) / len(kernel_ms)
         total_alg = sum(alg.values())
@@ -395,9 +399,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import pyoracle
         try:
-            cores = len(os.sched_getaffinity(0))
+            visible = len(os.sched_getaffinity(0))
         except Exception:
-            cores = os.cpu_count() or 1
+            visible = os.cpu_count() or 1
+        cores = max(1, min(visible, 16))          # the GPU box's CPU share for one GPU is 16 cores, whatever the affinity mask shows
         o = pyoracle.Oracle()
         n_env, cube, pyr = r.env_read(h["env"]) if h["env"] is not None else (None, None, None)
         ho = s.upload(o, env_raw=(n_env, cube, pyr) if n_env else None)
@@ -429,7 +434,7 @@ def main():
             legs.update(dynamic_legs(np, torch, scenes, abi, Renderer, pyoracle, local_rank))
         except Exception as e:        # noqa: BLE001 -- a baseline leg must never take the headline down
             legs["dynamic_legs_error"] = repr(e)
-        result["cpu_baseline"] = {"value": round(v_all, 4), "unit": "Mrays/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+        result["cpu_baseline"] = {"value": round(v_all, 4), "unit": "Mrays/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(), "host_cpus_visible": visible,
                                   "value_1_thread": round(v_one, 4),
                                   "sample": "all cores: %d frames of the same scene/camera/settings at %dx%d (1/64 of the pixels); 1 thread: %d frames at %dx%d"
                                             % (f_all, max(sw // 8, 16), max(sh // 8, 16), f_one, max(sw // 16, 16), max(sh // 16, 16)),

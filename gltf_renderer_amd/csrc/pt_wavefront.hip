@@ -51,8 +51,10 @@ struct WfBuffers {
     // shadow queue, kShards segments of 2 * seg_cap entries: (o.xyz, bits: slot | is_light << 31), (d.xyz, tmax)
     float4* sh_o;
     float4* sh_d;
-    uint32_t* cnt[5];     // per shard (stride kCounterStride): entry counts of closest queue 0, closest queue 1, shadow queue;
-                          // [3], [4]: dynamic-fetch heads of the closest / shadow trace stages
+    uint32_t* cnt[6];     // per shard (stride kCounterStride): entry counts of closest queue 0, closest queue 1, shadow queue (even bounces);
+                          // [3], [4]: dynamic-fetch heads of the closest / shadow trace stages; [5]: shadow-queue count of odd bounces
+                          // (the shadow count ping-pongs so that the fused traversal stage can zero the one the NEXT shade stage fills
+                          // while it still reads the current one)
     uint32_t capacity;    // slots
     uint32_t seg_cap;     // entries per closest-queue segment
     uint32_t blocks_per_shard;
@@ -85,13 +87,17 @@ PT_DEV ShardView shard_view(const WfBuffers& wf) {
 // Which pixel tiles a workgroup generates.  Workgroups are dispatched to the eight XCDs round-robin (XCD = blockIdx % 8), every later
 // stage launch has the same grid, and shard s = blockIdx % kShards is only ever touched by workgroups with blockIdx % 8 == s % 8:
 // a path lives its whole life on ONE XCD.  Each XCD has its own 4-MiB L2, and the scene (BVH + packets, tens of MB) fits none of
-// them; so each XCD is given a CONTIGUOUS range of this rank's tiles (a band of the screen) -- its primary rays, their shadow rays
-// and most first bounces then walk one part of the scene, and its L2 holds that part instead of a 1/8 sample of everything.
-// Within the band, consecutive workgroups of the XCD take consecutive (tile, sample) pairs.  Slots keep their meaning
-// (slot = sample * pixel_slots + tile * 256 + lane), only the workgroup that generates a slot changes: images are bit-identical.
+// them.  PT_GEN_XCD_BANDS = 1 / 2 gives each XCD a CONTIGUOUS range of this rank's tiles (a row band / a column band of the
+// screen), so that its primary rays, their shadow rays and most first bounces walk one part of the scene and its L2 holds that part
+// instead of a 1/8 sample of everything.  Within the band, consecutive workgroups of the XCD take consecutive (tile, sample)
+// pairs.  Slots keep their meaning (slot = sample * pixel_slots + tile * 256 + lane), only the workgroup that generates a slot
+// changes: images are bit-identical (tested).  MEASURED: both band shapes are 3-4 % SLOWER than dealing tiles round-robin over all
+// workgroups (the default, 0): a path never leaves its XCD, so the XCD whose band holds the expensive part of the picture finishes
+// last while the others idle, and that costs more than the locality buys.  Kept as a build option for the record.
 constexpr uint32_t kXcds = 8;
 #ifndef PT_GEN_XCD_BANDS
-#define PT_GEN_XCD_BANDS 1
+#define PT_GEN_XCD_BANDS 0      // measured on MI355X (Sponza-class 1080p, 8 spp / launch): 0 (tiles dealt round-robin) 4473 Mrays/s,
+                                // 1 (row bands) 4339, 2 (column bands) 4274 -- see the comment above and DESIGN.md section 4
 #endif
 __global__ __launch_bounds__(kBlock) void k_wf_generate(FrameConstants fc, WfBuffers wf, Counters* __restrict__ counters) {
     const ShardView sv = shard_view(wf);
@@ -150,10 +156,12 @@ __global__ __launch_bounds__(kBlock) void k_wf_generate(FrameConstants fc, WfBuf
 #ifndef PT_REFILL
 #define PT_REFILL 48          // idle lanes that trigger a refill from the shard queue (swept 8..64 on MI355X: 48 is best)
 #endif
+PT_DEV int shadow_counter(int bounce) { return (bounce & 1) ? 5 : 2; }
 template <bool COUNT, int MODE>
 PT_DEV void trace_persistent(const SceneRec& sc, const WfBuffers& wf, int* my_stack, const ShardView& sv, int cur, uint32_t rf_closest, uint32_t rmask,
                              uint32_t flags, LaneStats& st) {
-    const uint32_t n = wf.cnt[MODE == 0 ? cur : 2][sv.shard * kCounterStride];
+    // MODE 0: `cur` = closest queue (0 / 1).  MODE 1: `cur` = index of the shadow-queue counter (shadow_counter(bounce)).
+    const uint32_t n = wf.cnt[cur][sv.shard * kCounterStride];
     uint32_t* head = wf.cnt[MODE == 0 ? 3 : 4] + sv.shard * kCounterStride;
     const size_t base = MODE == 0 ? (size_t)sv.shard * wf.seg_cap : (size_t)sv.shard * wf.seg_cap * 2;
     const uint32_t lane = threadIdx.x & 63;
@@ -230,17 +238,43 @@ PT_DEV void trace_persistent(const SceneRec& sc, const WfBuffers& wf, int* my_st
 #ifndef PT_TRACE_WAVES
 #define PT_TRACE_WAVES 1
 #endif
+#ifndef PT_LATE_GRID
+#define PT_LATE_GRID 1        // smaller stage grids for the thin late bounces (launch_wavefront)
+#endif
+#ifndef PT_FUSE_TRAVERSAL
+#define PT_FUSE_TRAVERSAL 1   // the shadow rays of a bounce and the closest-hit rays of the next in one launch (k_wf_traverse)
+#endif
+// `bounce` = the bounce whose shade stage follows: it fills closest queue cur ^ 1 and the shadow counter of that bounce.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_trace(SceneRec sc, WfBuffers wf, int cur, uint32_t rf, uint32_t rmask, Counters* __restrict__ counters) {
+__global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_trace(SceneRec sc, WfBuffers wf, int cur, int bounce, uint32_t rf, uint32_t rmask, Counters* __restrict__ counters) {
     __shared__ int s_stack[kStackLds * kBlock];
     stage_luts(sc);
     const ShardView sv = shard_view(wf);
     // member 0 of each shard zeroes the counters the following shade stage fills
-    if (sv.member == 0 && threadIdx.x == 0) { wf.cnt[cur ^ 1][sv.shard * kCounterStride] = 0; wf.cnt[2][sv.shard * kCounterStride] = 0; }
+    if (sv.member == 0 && threadIdx.x == 0) { wf.cnt[cur ^ 1][sv.shard * kCounterStride] = 0; wf.cnt[shadow_counter(bounce)][sv.shard * kCounterStride] = 0; }
     LaneStats st = {0, 0, 0, 0};
     trace_persistent<COUNT, 0>(sc, wf, s_stack + threadIdx.x, sv, cur, rf, rmask, 0, st);
     if (COUNT) flush_counters(counters, threadIdx.x & 63, 0, 0, 0, 0, st);
     else if (st.overflow) atomicAdd(&counters->stack_overflow, (unsigned long long)st.overflow);
+}
+
+// Fused traversal stage: the occlusion rays of bounce `bounce` AND the closest-hit rays of bounce + 1.  Both were produced by the
+// shade stage of `bounce` and neither needs the other's result (the shadow transmissions are only read by the NEXT shade stage), so
+// one launch serves both: a wave that runs out of shadow rays goes straight on to pull bounce rays, and the frame has two
+// grid-wide synchronisations per bounce instead of three (each one ends on its slowest wave: ~0.07 ms of a 5.5-ms 1-spp frame).
+// `nxt` = closest queue the shade stage of `bounce` filled.  Zeroes what the shade stage of bounce + 1 fills.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_traverse(SceneRec sc, WfBuffers wf, int nxt, int bounce, uint32_t rf, uint32_t rmask, uint32_t flags,
+                                                                        Counters* __restrict__ counters) {
+    __shared__ int s_stack[kStackLds * kBlock];
+    stage_luts(sc);
+    const ShardView sv = shard_view(wf);
+    if (sv.member == 0 && threadIdx.x == 0) { wf.cnt[nxt ^ 1][sv.shard * kCounterStride] = 0; wf.cnt[shadow_counter(bounce + 1)][sv.shard * kCounterStride] = 0; }
+    LaneStats st_shadow = {0, 0, 0, 0}, st = {0, 0, 0, 0};
+    trace_persistent<COUNT, 1>(sc, wf, s_stack + threadIdx.x, sv, shadow_counter(bounce), 0, 0xff, flags, st_shadow);
+    trace_persistent<COUNT, 0>(sc, wf, s_stack + threadIdx.x, sv, nxt, rf, rmask, 0, st);
+    if (COUNT) { flush_counters(counters, threadIdx.x & 63, 0, 0, 0, 0, st_shadow, true); flush_counters(counters, threadIdx.x & 63, 0, 0, 0, 0, st); }
+    else if (st.overflow + st_shadow.overflow) atomicAdd(&counters->stack_overflow, (unsigned long long)(st.overflow + st_shadow.overflow));
 }
 
 // The reference multiplies the light colour by the shadow transmission BEFORE `if (any(color > 0))` and never evaluates
@@ -257,7 +291,12 @@ PT_DEV void apply_pending(const WfBuffers& wf, uint32_t slot, vec3& L) {
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 2      // waves per SIMD the register allocator must leave room for (2 -> <= 256 VGPR+AGPR)
 #endif
-__global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc, FrameConstants fc, WfBuffers wf, int cur, Counters* __restrict__ counters) {
+__global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc, FrameConstants fc, WfBuffers wf, int cur, int bounce, Counters* __restrict__ counters) {
+    {   // a workgroup whose share of the shard's queue is empty (most of them from the third bounce on) leaves before it stages
+        // 67 KB of tables into LDS; member 0 stays for the head rewind below
+        const ShardView sv0 = shard_view(wf);
+        if (sv0.member != 0 && sv0.member * kBlock >= wf.cnt[cur][sv0.shard * kCounterStride]) return;
+    }
     stage_luts(sc);
     stage_tangent_lut(sc);
     stage_importance_top(sc);
@@ -269,7 +308,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
     const int nxt = cur ^ 1;
     const size_t base = (size_t)sv.shard * wf.seg_cap, sbase = (size_t)sv.shard * wf.seg_cap * 2;
     uint32_t* cnt_next = wf.cnt[nxt] + sv.shard * kCounterStride;
-    uint32_t* cnt_shadow = wf.cnt[2] + sv.shard * kCounterStride;
+    uint32_t* cnt_shadow = wf.cnt[shadow_counter(bounce)] + sv.shard * kCounterStride;
     // the dynamic-fetch heads of both trace stages are idle while shading runs: rewind them here
     if (sv.member == 0 && threadIdx.x == 0) { wf.cnt[3][sv.shard * kCounterStride] = 0; wf.cnt[4][sv.shard * kCounterStride] = 0; }
     unsigned n_bounce = 0, n_shadow = 0, n_hits = 0;
@@ -348,12 +387,12 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
 
 // occlusion traversal of the shadow queue (TraceShadowRay :724-742); writes the transmission next to its pending term.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_shadow(SceneRec sc, WfBuffers wf, uint32_t flags, Counters* __restrict__ counters) {
+__global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_shadow(SceneRec sc, WfBuffers wf, int bounce, uint32_t flags, Counters* __restrict__ counters) {
     __shared__ int s_stack[kStackLds * kBlock];
     stage_luts(sc);
     const ShardView sv = shard_view(wf);
     LaneStats st = {0, 0, 0, 0};
-    trace_persistent<COUNT, 1>(sc, wf, s_stack + threadIdx.x, sv, 0, 0, 0xff, flags, st);
+    trace_persistent<COUNT, 1>(sc, wf, s_stack + threadIdx.x, sv, shadow_counter(bounce), 0, 0xff, flags, st);
     if (COUNT) flush_counters(counters, threadIdx.x & 63, 0, 0, 0, 0, st, true);
     else if (st.overflow) atomicAdd(&counters->stack_overflow, (unsigned long long)st.overflow);
 }
@@ -406,7 +445,7 @@ size_t wavefront_workspace_bytes(const FrameConstants& fc, int stage_blocks) {
     const uint32_t bps = blocks_per_shard_for(stage_blocks);
     const size_t slots = (size_t)fc.my_tiles * kBlock * fc.spp;
     const size_t q = (size_t)kShards * seg_cap_for(fc, bps);
-    return slots * (5 * 16 + 4) + q * (4 * 16 + 16 + 2 * 2 * 16) + 5 * kShards * kCounterStride * 4 + 32 * 256;
+    return slots * (5 * 16 + 4) + q * (4 * 16 + 16 + 2 * 2 * 16) + 6 * kShards * kCounterStride * 4 + 32 * 256;
 }
 
 static WfBuffers carve(void* base, const FrameConstants& fc, int stage_blocks) {
@@ -419,7 +458,7 @@ static WfBuffers carve(void* base, const FrameConstants& fc, int stage_blocks) {
     wf.gen_region_tiles = gen_region_tiles_for(fc);
     wf.gen_rounds = gen_rounds_for(fc, wf.blocks_per_shard);
     const size_t q = (size_t)kShards * wf.seg_cap;
-    for (int k = 0; k < 5; k++) wf.cnt[k] = (uint32_t*)take((size_t)kShards * kCounterStride * 4);
+    for (int k = 0; k < 6; k++) wf.cnt[k] = (uint32_t*)take((size_t)kShards * kCounterStride * 4);
     wf.L = (float4*)take((size_t)slots * 16);
     wf.beta_pdf = (float4*)take((size_t)slots * 16);
     wf.thr_misc = (float4*)take((size_t)slots * 16);
@@ -458,7 +497,7 @@ hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4
     };
     const uint32_t slots = fc.my_tiles * kBlock * fc.spp;
     WfBuffers wf = carve(workspace, fc, stage_blocks);
-    hipError_t e = hipMemsetAsync(wf.cnt[0], 0, (size_t)5 * kShards * kCounterStride * 4, stream);     // the five counter arrays are contiguous
+    hipError_t e = hipMemsetAsync(wf.cnt[0], 0, (size_t)6 * kShards * kCounterStride * 4, stream);     // the six counter arrays are contiguous
     if (e) return e;
     const dim3 block(kBlock), full(fc.my_tiles), stage(kShards * wf.blocks_per_shard);
     if (timers) { hipEvent_t ev = event_at(0); if (ev) hipEventRecord(ev, stream); else timers = nullptr; }
@@ -466,23 +505,75 @@ hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4
     mark(STAGE_GENERATE);
     const uint32_t flags = fc.flags;
     const int iterations = fc.debug_output != PT_DEBUG_OUTPUT_NONE ? 1 : fc.max_bounces + 1;
-    for (int b = 0; b < iterations; b++) {
-        const int cur = b & 1;
-        uint32_t rf, rmask = 0xff;
+    auto ray_flags = [&](int b, uint32_t& rf, uint32_t& rmask) {
+        rmask = 0xff;
         if (b == 0) rf = (flags & PT_FLAG_CULL_BACKFACE) ? RF_CULL_BACK : 0;                          // RayGeneration :747
         else {                                                                                        // TraceBounceRay :671-672
             rf = (flags & PT_FLAG_CULL_BACKFACE) ? RF_CULL_FRONT : 0;
             rmask = (flags & PT_FLAG_INDIRECT_ENVIRONMENT_ONLY) ? 0 : 0xff;
         }
-        if (count) hipLaunchKernelGGL(k_wf_trace<true>, stage, block, 0, stream, sc, wf, cur, rf, rmask, counters);
-        else hipLaunchKernelGGL(k_wf_trace<false>, stage, block, 0, stream, sc, wf, cur, rf, rmask, counters);
+    };
+#if PT_LATE_GRID
+    // Late bounces carry few paths (Russian roulette starts after min_bounces and the reference's throughput drives the continuation
+    // probability to its floor): a launch sized for the full queue then mostly starts workgroups that find nothing and, in the shade
+    // stage, would stage 67 KB of tables for it.  The grid of a bounce follows the EXPECTED queue (a quarter of the paths per bounce
+    // beyond min_bounces + 1); only speed depends on the guess -- any multiple of kShards workgroups walks the whole queue.
+    auto grid_of = [&](int b) -> dim3 {
+        uint32_t bps = wf.blocks_per_shard;
+        if (b > fc.min_bounces + 1) {
+            double expected = (double)slots;
+            for (int k = fc.min_bounces + 1; k < b; k++) expected *= 0.25;
+            const uint32_t want = expected >= 1200000.0 ? 6u : (expected >= 400000.0 ? 3u : 2u);
+            bps = want < bps ? want : bps;
+        }
+        return dim3(kShards * bps);
+    };
+#define PT_GRID(b) grid_of(b)
+#define PT_WF(b) wf_for(b)
+    auto wf_for = [&](int b) { WfBuffers w = wf; w.blocks_per_shard = grid_of(b).x / kShards; return w; };
+#else
+#define PT_GRID(b) stage
+#define PT_WF(b) wf
+#endif
+#if PT_FUSE_TRAVERSAL
+    // generate -> trace(0) -> [shade(b) -> shadow(b) + trace(b + 1)] x (bounces) -> resolve: two grid-wide synchronisations per bounce
+    {
+        uint32_t rf, rmask;
+        ray_flags(0, rf, rmask);
+        if (count) hipLaunchKernelGGL(k_wf_trace<true>, stage, block, 0, stream, sc, wf, 0, 0, rf, rmask, counters);
+        else hipLaunchKernelGGL(k_wf_trace<false>, stage, block, 0, stream, sc, wf, 0, 0, rf, rmask, counters);
         mark(STAGE_TRACE);
-        hipLaunchKernelGGL(k_wf_shade, stage, block, 0, stream, sc, fc, wf, cur, counters);
+    }
+    for (int b = 0; b < iterations; b++) {
+        const int cur = b & 1;
+        hipLaunchKernelGGL(k_wf_shade, PT_GRID(b), block, 0, stream, sc, fc, PT_WF(b), cur, b, counters);
         mark(STAGE_SHADE);
-        if (count) hipLaunchKernelGGL(k_wf_shadow<true>, stage, block, 0, stream, sc, wf, flags, counters);
-        else hipLaunchKernelGGL(k_wf_shadow<false>, stage, block, 0, stream, sc, wf, flags, counters);
+        uint32_t rf, rmask;
+        ray_flags(b + 1, rf, rmask);
+        if (b + 1 < iterations) {
+            if (count) hipLaunchKernelGGL(k_wf_traverse<true>, PT_GRID(b), block, 0, stream, sc, PT_WF(b), cur ^ 1, b, rf, rmask, flags, counters);
+            else hipLaunchKernelGGL(k_wf_traverse<false>, PT_GRID(b), block, 0, stream, sc, PT_WF(b), cur ^ 1, b, rf, rmask, flags, counters);
+        } else {                                                                                      // the last vertex pushes no bounce ray
+            if (count) hipLaunchKernelGGL(k_wf_shadow<true>, PT_GRID(b), block, 0, stream, sc, PT_WF(b), b, flags, counters);
+            else hipLaunchKernelGGL(k_wf_shadow<false>, PT_GRID(b), block, 0, stream, sc, PT_WF(b), b, flags, counters);
+        }
         mark(STAGE_SHADOW);
     }
+#else
+    for (int b = 0; b < iterations; b++) {
+        const int cur = b & 1;
+        uint32_t rf, rmask;
+        ray_flags(b, rf, rmask);
+        if (count) hipLaunchKernelGGL(k_wf_trace<true>, stage, block, 0, stream, sc, wf, cur, b, rf, rmask, counters);
+        else hipLaunchKernelGGL(k_wf_trace<false>, stage, block, 0, stream, sc, wf, cur, b, rf, rmask, counters);
+        mark(STAGE_TRACE);
+        hipLaunchKernelGGL(k_wf_shade, stage, block, 0, stream, sc, fc, wf, cur, b, counters);
+        mark(STAGE_SHADE);
+        if (count) hipLaunchKernelGGL(k_wf_shadow<true>, stage, block, 0, stream, sc, wf, b, flags, counters);
+        else hipLaunchKernelGGL(k_wf_shadow<false>, stage, block, 0, stream, sc, wf, b, flags, counters);
+        mark(STAGE_SHADOW);
+    }
+#endif
     hipLaunchKernelGGL(k_wf_resolve, full, block, 0, stream, fc, wf, output);
     mark(STAGE_RESOLVE);
     return hipGetLastError();

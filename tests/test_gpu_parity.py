@@ -54,7 +54,13 @@ class Pair:
 
 
 def rel_l2(a, b):
-    return float(np.sqrt(((a.astype(np.float64) - b) ** 2).sum() / max((b.astype(np.float64) ** 2).sum(), 1e-30)))
+    """Relative L2 over the pixels finite on both sides (AgX ends in pow(x, 2.2) of a value that can be slightly negative for very
+    dark pixels, ToneMapper.ps.hlsl:75: NaN upstream, in the oracle and here alike -- those pixels must coincide)."""
+    a = a.astype(np.float64); b = b.astype(np.float64)
+    fa, fb = np.isfinite(a), np.isfinite(b)
+    assert (fa != fb).mean() < 1e-3, float((fa != fb).mean())
+    ok = fa & fb
+    return float(np.sqrt(((a[ok] - b[ok]) ** 2).sum() / max((b[ok] ** 2).sum(), 1e-30)))
 
 
 @pytest.fixture(scope="module")
@@ -124,11 +130,12 @@ def test_radiance_parity_flag_matrix(pair, name, set_flags, clear_flags):
     st.reset = 1
     og, b = pair.render(settings=st, frames=1)                  # first frame with reset ...
     st.reset = 0
-    for f in range(1, 16):                                      # ... then accumulate
+    for f in range(1, 64):                                      # ... then accumulate
         pair.r.trace(st, pair.s.execute_params(frame=f, env_handle=pair.hg["env"]), og)
         pair.o.trace(st, pair.s.execute_params(frame=f, env_handle=pair.ho["env"]), b)
     r = rel_l2(pair.r.tonemap(og), po.tonemap(b))
-    assert r <= 2e-3, (name, r)                                 # 16 spp: one flipped sample weighs 1/16 of a pixel
+    print("flag matrix %s: tone-mapped rel L2 %.3e at 64 spp" % (name, r))
+    assert r <= 1e-3, (name, r)                                 # the north_star bar (64 spp: one flipped sample weighs 1/64 of a pixel)
     st2 = pair.r.stats(); c = pair.o.counters()
     assert abs(int(st2.rays) - c["rays"]) <= 3e-4 * c["rays"] + 2, name
 
@@ -136,19 +143,27 @@ def test_radiance_parity_flag_matrix(pair, name, set_flags, clear_flags):
 def test_constant_environment_no_envmap(R, oracle_lib):
     import oracle.pyoracle as po
     p = Pair(R, oracle_lib, scenes.test_scene(64, 32, with_env=False))
-    og, b = p.render(frames=16)
-    assert rel_l2(p.r.tonemap(og), po.tonemap(b)) <= 1.5e-3
+    og, b = p.render(frames=64)
+    e = rel_l2(p.r.tonemap(og), po.tonemap(b))
+    print("constant environment: tone-mapped rel L2 %.3e at 64 spp" % e)
+    assert e <= 1e-3, e
     p.close()
 
 
 def test_material_grid_deep_bounces(R, oracle_lib):
     """config-4 class (transmission / clearcoat / sheen / anisotropy sweeps), 16 bounces with the clamp lifted."""
     import oracle.pyoracle as po
-    p = Pair(R, oracle_lib, scenes.material_grid(96, seg=12))
-    og, b = p.render(frames=16)
-    assert rel_l2(p.r.tonemap(og), po.tonemap(b)) <= 2e-3
+    # 160^2 at 128 spp.  (At 96^2 / 64 spp this scene sat at 1.36e-3: tools/diag_grid.py shows 84 % of that squared error in ONE
+    # 12 x 12 block, a smooth transmissive sphere where one flipped path reaches the 2e3-radiance sun on one side only -- a single
+    # saturated pixel of a 96^2 image is already 1e-2.  More pixels and samples put the same event below the bar; no bias:
+    # the signed mean difference is 1e-5 of the mean.)
+    p = Pair(R, oracle_lib, scenes.material_grid(160, seg=12))
+    og, b = p.render(frames=128)
+    e = rel_l2(p.r.tonemap(og), po.tonemap(b))
+    print("material grid, 16 bounces: tone-mapped rel L2 %.3e at 160^2, 128 spp" % e)
     st = p.r.stats(); c = p.o.counters()
     assert abs(int(st.rays) - c["rays"]) <= 5e-4 * c["rays"]
+    assert e <= 1e-3, e
     p.close()
 
 
@@ -355,10 +370,12 @@ def test_skinned_frame_renders_like_oracle(R, oracle_lib):
     og = r.create_output(s.width, s.height); b = np.zeros((s.height, s.width, 4), np.float32)
     env_raw = r.env_read(hg["env"])
     eo = o.env_create_raw(*env_raw)
-    for f in range(16):
+    for f in range(64):
         r.trace(s.settings, s.execute_params(f, env_handle=hg["env"]), og)
         o.trace(s.settings, s.execute_params(f, env_handle=eo), b)
-    assert rel_l2(r.tonemap(og), po.tonemap(b)) <= 2e-3
+    e = rel_l2(r.tonemap(og), po.tonemap(b))
+    print("skinned frame: tone-mapped rel L2 %.3e at 64 spp" % e)
+    assert e <= 1e-3, e
     r.close(); o.close(); o2.close()
 
 
@@ -446,10 +463,12 @@ def test_tables_larger_than_the_lds_caches(R, oracle_lib):
         err = np.abs(p.r.readback(og)[..., :3] - b[..., :3]).max(axis=2)
         assert (err > 1e-4).mean() < 0.003, (abi.DEBUG_OUTPUT_NAMES[dbg], float((err > 1e-4).mean()))
     import oracle.pyoracle as po
-    og, b = p.render(frames=16)
-    assert rel_l2(p.r.tonemap(og), po.tonemap(b)) <= 2e-3
+    og, b = p.render(frames=64)
+    e = rel_l2(p.r.tonemap(og), po.tonemap(b))
+    print("tables beyond the LDS caches: tone-mapped rel L2 %.3e at 64 spp" % e)
     sg, so = p.r.stats(), p.o.counters()
     assert abs(int(sg.rays) - so["rays"]) <= 3e-4 * so["rays"] + 2
+    assert e <= 1e-3, e
     p.close()
 
 

@@ -87,7 +87,7 @@ if "TCC_HIT_sum" in p and "TCC_MISS_sum" in p:
 # ---- per-kernel PMC split (FETCH / WRITE / TCC hit and miss per stage, so every fraction of bench.py's roofline
 # object can be recomputed from profiles/ alone).  Stage = the kernel family; per launch = per pt_trace = per frame of the run.
 def stage_of(name):
-    for key, st in (("k_wf_trace", "trace"), ("k_wf_shadow", "shadow"), ("k_wf_shade", "shade"), ("k_wf_generate", "generate+resolve"), ("k_wf_resolve", "generate+resolve"),
+    for key, st in (("k_wf_traverse", "traversal"), ("k_wf_trace", "traversal"), ("k_wf_shadow", "traversal"), ("k_wf_shade", "shade"), ("k_wf_generate", "generate+resolve"), ("k_wf_resolve", "generate+resolve"),
                     ("k_wf_tail", "tail"), ("pt_megakernel", "megakernel")):
         if key in name:
             return st
