@@ -438,6 +438,7 @@ PT_DEV Surface get_surface(const SceneRec& sc, uint32_t flags, const RMat* m, co
     s.sheen_color = h.sheen_color_factor;                                                         // :210-217
     float sheen_rough = h.sheen_roughness_factor;                                                 // :219-226
     s.transmissive = h.transmission_factor;                                                       // :228-235
+#ifndef PT_PROBE_BASE_ONLY
     if (h.bound_mask >> SLOT_SPECULAR) {                   // any of the rarely-bound extension textures (slots 5..14)
         if (slot_bound(h.bound_mask, SLOT_SPECULAR)) s.spec_factor *= sample_slot(sc, m, SLOT_SPECULAR, a.tc, taps).w;
         if (slot_bound(h.bound_mask, SLOT_SPECULAR_COLOR)) s.spec_color = s.spec_color * xyz(sample_slot(sc, m, SLOT_SPECULAR_COLOR, a.tc, taps));
@@ -454,6 +455,7 @@ PT_DEV Surface get_surface(const SceneRec& sc, uint32_t flags, const RMat* m, co
         if (slot_bound(h.bound_mask, SLOT_TRANSMISSION)) s.transmissive *= sample_slot(sc, m, SLOT_TRANSMISSION, a.tc, taps).x;
         if (slot_bound(h.bound_mask, SLOT_THICKNESS)) taps++;   // thickness is loaded upstream but unused (quirk q14)
     }
+#endif
     if (flags & PT_FLAG_SHADING_NORMAL_ADAPTATION) s.cc_n = normal_adaptation(a.ng, s.cc_n, view);
     const float cr = h.anisotropy_cos, sr = h.anisotropy_sin;
     vec2 adir = normalize(vec2{cr * av.x + -sr * av.y, sr * av.x + cr * av.y});
@@ -553,12 +555,14 @@ PT_DEV vec3 gltf_bsdf(const float* lut, const Surface& s, vec3 v, vec3 l, int mo
     float spec = refl ? saturate(ll.z) * aniso_specular_brdf(s.ax, s.ay, vl, hl, ll) : 0.f;
     vec3 diffuse = refl ? saturate(ll.z) * (s.albedo / kPi) : v3(0);
     vec3 transmission = v3(0);
+#ifndef PT_PROBE_BASE_ONLY
     if (trans) {                                           // ThinSurfaceTransmissionBtdf :222-228
         float a = modulate_roughness(s.ay, s.ior);
         vec3 lr = l - 2 * dot(n, l) * n;
         vec3 hr = normalize(v + lr);
         transmission = saturate(-ll.z) * (s.albedo * specular_brdf(a, dot(n, lr), dot(n, v), dot(n, hr), dot(hr, lr), dot(hr, v)));
     }
+#endif
     diffuse = lerp3(diffuse, transmission, s.transmissive);
     // FresnelMix :137-144
     float f0s = (1 - s.ior) / (1 + s.ior);
@@ -570,7 +574,11 @@ PT_DEV vec3 gltf_bsdf(const float* lut, const Surface& s, vec3 v, vec3 l, int mo
     vec3 metal = refl ? v3(spec) * schlick3(s.albedo, hdv) : v3(0);                // ConductorFresnel :146-149
     vec3 material = lerp3(dielectric, metal, s.metalness);
     float sa = clampf(s.sheen_a, 0.000001f, 1);
+#ifndef PT_PROBE_BASE_ONLY
     vec3 sheen = refl ? v3(saturate(ll.z) * sheen_brdf(sa, ll.z, vl.z, hl.z)) : v3(0);
+#else      // PROBE ONLY (tools/build_variant.sh): what the extension lobes cost a hit that has none; wrong for materials that do
+    vec3 sheen = v3(0);
+#endif
     float ms = max3(s.sheen_color);                                               // SheenMix :210-214
     // Without sheen (ms == 0) both terms are 1 - 0 * E = 1 exactly (E is always finite: sheen_e clamps NaN coordinates):
     // skip the eight table gathers.
@@ -578,7 +586,11 @@ PT_DEV vec3 gltf_bsdf(const float* lut, const Surface& s, vec3 v, vec3 l, int mo
     if (ms != 0.0f) scaling = hmin(1.0f - ms * sheen_e(lut, sa, vl.z), 1.0f - ms * sheen_e(lut, sa, ll.z));
     material = s.sheen_color * sheen + material * scaling;
     float cndv = dot(n, v), cndh = dot(n, h), cndl = dot(n, l);                    // (sic) shading normal
+#ifndef PT_PROBE_BASE_ONLY
     float cc = refl ? saturate(cndl) * specular_brdf(s.cc_rough, cndl, cndv, cndh, hdl, hdv) : 0.f;
+#else
+    float cc = 0.f;
+#endif
     return lerp3(material, v3(cc), fresnel_coat_w(s.clearcoat, cndv));             // FresnelCoat(1.5, ...)
 }
 
@@ -881,6 +893,10 @@ PT_DEV vec2 sample_importance_map(const EnvRec& e, float ux, float uy, float& pd
     // The reference descends ten levels with four dependent point loads each.  Here one 64-B fetch of a 4x4 block of the
     // finer level of a pair serves two levels: the coarser level's 2x2 values are re-summed from the block in the order the
     // pyramid build uses (k_importance_level: ((ul + ll) + ur) + lr), which reproduces the stored sums bit for bit.
+#ifdef PT_PROBE_NO_DESCENT      // PROBE ONLY: what the five-level descent costs the shade stage (wrong sampling, timing only)
+    pdf = 1.0f;
+    return {ux, uy};
+#endif
     uint32_t px = 0, py = 0;
     float value = 0.f;
 #pragma unroll 1

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Rehearsal on a 1-GPU box: N ranks (gloo, all on cuda:0) render their tile shards of one frame and assemble it on rank 0
-with both exchange forms of gltf_renderer_amd/sharding.py; rank 0 also renders the whole frame alone.  All three must be
+with both exchange forms of the torch.distributed test double (gltf_renderer_amd/sharding.py) -- and moves the tiles through
+libmipt.so's own pack / unpack kernels (pt_tiles_pack / pt_tiles_unpack, the device half of pt_exchange_frame) --; rank 0 also renders the whole frame alone.  All three must be
 bit-identical.  Launch:  python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/check_exchange.py"""
 import os
 import sys
@@ -19,7 +20,7 @@ def main():
     dist.init_process_group("gloo")
     from gltf_renderer_amd import abi, scenes
     from gltf_renderer_amd.renderer import Renderer
-    from gltf_renderer_amd.sharding import TileExchange, reduce_frame
+    from gltf_renderer_amd.sharding import TileExchange
     s = scenes.test_scene(200, 64)
     s.width, s.height = 200, 136                       # partial edge tiles in both directions
     r = Renderer(0)
@@ -32,20 +33,30 @@ def main():
     torch.cuda.synchronize()
     host = mine.cpu()
     gathered = host.clone()
-    TileExchange(s.width, s.height, world, "cpu").gather_frame(gathered, rank)
-    tx, ty = (s.width + 15) // 16, (s.height + 15) // 16
-    y, x = np.mgrid[0:s.height, 0:s.width]
-    own = torch.from_numpy((((y // 16) * tx + (x // 16)) % world) == rank)
-    summed = torch.where(own[..., None], host, torch.zeros_like(host))
-    reduce_frame(summed, world)
+    xch = TileExchange(s.width, s.height, world, "cpu")
+    xch.gather_frame(gathered, rank)
+    summed = xch.reduce_frame(host, rank)
+    # the library's own packing: my tiles packed on the GPU, gathered over gloo, unpacked on rank 0's GPU
+    packed = r.tiles_pack(mine, rank, world)
+    torch.cuda.synchronize()
+    sizes = [r.tiles_packed_bytes(s.width, s.height, k, world) // 16 for k in range(world)]
+    pad = torch.zeros((max(sizes), 4), dtype=torch.float32)
+    pad[: sizes[rank]] = packed.cpu()
+    parts = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, parts, dst=0)
+    if rank == 0:
+        frame = torch.full_like(mine, float("nan"))
+        for k in range(world):
+            r.tiles_unpack(parts[k][: sizes[k]].cuda(), frame, k, world)
+        torch.cuda.synchronize()
     if rank == 0:
         full = r.create_output(s.width, s.height)
         r.trace(st, s.execute_params(frame=5, env_handle=h["env"]), full)
         torch.cuda.synchronize()
         f = full.cpu()
-        ok_g, ok_r = bool(torch.equal(gathered, f)), bool(torch.equal(summed, f))
-        print("world %d: gather == full frame: %s, reduce == full frame: %s" % (world, ok_g, ok_r))
-        if not (ok_g and ok_r):
+        ok_g, ok_r, ok_p = bool(torch.equal(gathered, f)), bool(torch.equal(summed, f)), bool(torch.equal(frame.cpu(), f))
+        print("world %d: gather == full frame: %s, reduce == full frame: %s, pt_tiles_pack/unpack == full frame: %s" % (world, ok_g, ok_r, ok_p))
+        if not (ok_g and ok_r and ok_p):
             sys.exit(1)
     dist.barrier()
     dist.destroy_process_group()
