@@ -383,7 +383,11 @@ __device__ void collapse_one(const BvhNode* __restrict__ nodes2, uint32_t binary
         const BvhNode& m = nodes2[ref[pick]];
         const ChildRanges mr = child_ranges(m);
         ref[pick] = child_ref(m.child0, mr.f0, mr.k0); ref[cnt] = child_ref(m.child1, mr.f1, mr.k1);
-        wr.first[pick] = mr.f0; wr.count[pick] = mr.k0; wr.first[cnt] = mr.f1; wr.count[cnt] = mr.k1;
+#pragma unroll
+        for (int k = 0; k < kBvhWidth; k++) {                  // (static indices: a dynamically indexed local array lives in scratch)
+            if (k == pick) { wr.first[k] = mr.f0; wr.count[k] = mr.k0; }
+            if (k == cnt) { wr.first[k] = mr.f1; wr.count[k] = mr.k1; }
+        }
         for (int a = 0; a < 3; a++) { lo[pick][a] = m.lo0[a]; hi[pick][a] = m.hi0[a]; lo[cnt][a] = m.lo1[a]; hi[cnt][a] = m.hi1[a]; }
         cnt++;
     }
