@@ -26,6 +26,8 @@ int pt_scene_set_lights(pt_ctx*, const pt_light*, int) { return -1; }
 int pt_scene_set_instances(pt_ctx*, const pt_instance_desc*, int) { return -1; }
 int pt_skin_run(pt_ctx*, const pt_skin_params*, const pt_bone*, int) { return -1; }
 const char* pt_last_error(const pt_ctx*) { return "stub"; }
+int pt_buffer_destroy(pt_ctx*, int) { return -1; }
+int pt_texture_destroy(pt_ctx*, int) { return -1; }
 }
 
 static uint64_t rng_state = 1;

@@ -193,3 +193,44 @@ def test_golden_tile_regression(oracle_lib):
     o = oracle_lib.Oracle(); h = s.upload(o)
     out = render(o, s, h, frames=4)
     assert np.allclose(out, gold, rtol=2e-5, atol=2e-6)
+
+
+def test_orthographic_camera_projects_in_parallel(oracle_lib):
+    """Camera::Orthographic (Camera.h:31-40, GetViewToClip :91: orthoRH_ZO(-1/x_mag, 1/x_mag, -1/y_mag, 1/y_mag, far, near)): the image
+    is the parallel projection of the scene onto the view plane, half extents 1 / mag (sic), top of the image = world +Z."""
+    s = scenes.single_triangle(128)
+    s.ortho = (0.5, 0.5)                                        # half extents 2 x 2
+    o = oracle_lib.Oracle(); h = s.upload(o)
+    st = copy_settings(s.settings); st.debug_output = abi.DEBUG_OUTPUT_HIT_KIND
+    out = render(o, s, h, settings=st)
+    hit = ((out[..., 0] == 1) & (out[..., 1] == 0)) | ((out[..., 0] == 0) & (out[..., 1] == 1))      # red front / green back; a miss is the white environment
+    # triangle (-1,0,-1) (1,0,-1) (0,0,1) seen along +Y: x in [-2, 2] left to right, z in [2, -2] top to bottom
+    ys, xs = np.mgrid[0:128, 0:128]
+    x = ((xs + 0.5) / 128 * 2 - 1) * 2.0
+    z = -((ys + 0.5) / 128 * 2 - 1) * 2.0
+    inside = (z > -1) & (z < 1 - 2 * np.abs(x))
+    assert (hit != inside).mean() < 0.01                        # the jittered silhouette pixels only
+    assert abs(hit.mean() - 2.0 / 16.0) < 0.003                 # area 2 of a 4 x 4 window, independent of the distance
+
+
+def test_skin_joint_ids_beyond_the_bone_array_read_zero(oracle_lib):
+    """Skin.cs.hlsl:93-101 index StructuredBuffer<Bone> with the vertex's raw joint ids; beyond the buffer D3D12's robust access
+    returns zeros, i.e. a zero matrix: the joint contributes nothing (it does not crash and it does not read a neighbour)."""
+    s = scenes.skinned_figure(16, 16)
+    sk = s.skins[0]
+    nv = sk["mesh"].num_vertices
+    res = []
+    for beyond in (False, True):
+        jw = s.buffers[sk["joint_weight"]][0].copy().reshape(-1, 8)
+        if beyond:
+            jw[:, 2] = 40000                                    # the third joint of every vertex: far beyond the 19 bones
+        else:
+            jw[:, 6] = 0                                        # reference: the third joint's weight set to zero instead
+        s2 = scenes.skinned_figure(16, 16)
+        s2.buffers[sk["joint_weight"]] = (jw, abi.FORMAT_JOINT_WEIGHT)
+        o = oracle_lib.Oracle(); h = s2.upload(o)
+        b = scenes.SkinBinding(o, s2, h, 0, 0)
+        b.pose(0.6)
+        res.append(o.buffer_read(b.out_position, np.float32, nv * 3))
+        o.close()
+    assert np.array_equal(res[0], res[1])
