@@ -242,6 +242,7 @@ class PtStats(C.Structure):
 
 STAGE_NAMES = ("generate", "trace", "shade", "shadow", "resolve")
 EXCHANGE_GATHER, EXCHANGE_REDUCE = 0, 1
+BUILDER_LBVH, BUILDER_PLOC = 0, 1
 EXCHANGE_ID_BYTES = 128
 
 

@@ -468,18 +468,187 @@ __global__ __launch_bounds__(1024) void k_collapse_small(const BvhNode* __restri
     }
 }
 
+
+// ---- 4b. PLOC: parallel locally-ordered clustering (Meister & Bittner 2018) as the topology builder instead of the radix tree.
+// The radix tree splits at the highest differing Morton bit -- a spatial median whatever the geometry looks like; measured on the
+// Sponza-class scene its inner-node area (the expected node visits of a ray) is 58 root areas against 47 for a binned-SAH tree.
+// PLOC builds bottom-up from the same Morton order: every cluster looks at its 2 * kPlocRadius neighbours in the current cluster
+// array for the partner with the smallest joint surface area; pairs that chose each other merge; the survivors are compacted and
+// the rounds repeat until one cluster is left.  Every later step here (segment-tree fit, leaf clusters, collapse, refit) needs each
+// subtree to cover a CONTIGUOUS range of the triangle array, which clustering does not preserve, so the tree is laid out afterwards:
+// a top-down pass gives every node its range [first, first + count) in depth-first leaf order and the Karras-style index the other
+// kernels assume (a left child is named by the LAST leaf of its range, a right child by the FIRST of its own -- unique per inner
+// node, root = 0), and the triangle packets are gathered into that order.
+#ifndef PT_PLOC_RADIUS
+#define PT_PLOC_RADIUS 8        // neighbours looked at on either side while the array is long (measured 8 / 16 / 32 / 64 / 128 on the Sponza-class
+                                // scene: 4820 / 4749 / 4744 / 4761 / 4619 Mrays/s at 8 spp)
+#endif
+#ifndef PT_PLOC_RADIUS_TOP
+#define PT_PLOC_RADIUS_TOP 8    // ... and once fewer than kPlocTopClusters clusters are left (the upper levels of the tree)
+#endif
+constexpr int kPlocRadius = PT_PLOC_RADIUS, kPlocRadiusTop = PT_PLOC_RADIUS_TOP, kPlocRadiusMax = PT_PLOC_RADIUS > PT_PLOC_RADIUS_TOP ? PT_PLOC_RADIUS : PT_PLOC_RADIUS_TOP;
+constexpr uint32_t kPlocTopClusters = 16384;
+struct PlocCluster { float lo[3]; int32_t ref; float hi[3]; uint32_t count; };     // 32 B; ref < 0: leaf ~(Morton index), >= 0: temporary node id
+static_assert(sizeof(PlocCluster) == 32, "PlocCluster");
+// counters: [0] temporary nodes made, [4] / [5] cluster count of even / odd rounds, [8 + L] layout frontier size of level L
+constexpr int kPlocLevelBase = 8;
+
+__global__ __launch_bounds__(256) void k_ploc_init(const TriPacket* __restrict__ tris, uint32_t n, PlocCluster* __restrict__ c, uint32_t* __restrict__ counters) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { counters[0] = 0; counters[4] = n; counters[5] = n; }
+    if (i >= n) return;
+    const TriPacket& tp = tris[i];
+    const vec3 p = v3p(tp.v0), q = p + v3p(tp.e1), r = p + v3p(tp.e2);
+    const vec3 lo = hmin(hmin(p, q), r), hi = hmax(hmax(p, q), r);
+    PlocCluster o;
+    o.lo[0] = lo.x; o.lo[1] = lo.y; o.lo[2] = lo.z; o.ref = ~(int32_t)i;
+    o.hi[0] = hi.x; o.hi[1] = hi.y; o.hi[2] = hi.z; o.count = 1;
+    c[i] = o;
+}
+
+// the partner with the smallest joint surface area among the 2 * kPlocRadius neighbours; ties go to the lexicographically
+// smaller (min index, max index) pair, a strict total order on pairs, so the globally best pair always chooses each other
+__global__ __launch_bounds__(256) void k_ploc_nearest(const PlocCluster* __restrict__ c, const uint32_t* __restrict__ n_ptr, uint32_t* __restrict__ nn) {
+    __shared__ float s_lo[3][256 + 2 * kPlocRadiusMax], s_hi[3][256 + 2 * kPlocRadiusMax];
+    const uint32_t n = *n_ptr;
+    const int radius = n < kPlocTopClusters ? kPlocRadiusTop : kPlocRadius;
+    const int base = (int)(blockIdx.x * 256u) - radius;
+    if ((uint32_t)(blockIdx.x * 256u) >= n) return;
+    for (int k = threadIdx.x; k < 256 + 2 * radius; k += 256) {
+        const int g = base + k;
+        if (g >= 0 && (uint32_t)g < n) {
+            const PlocCluster& q = c[g];
+            s_lo[0][k] = q.lo[0]; s_lo[1][k] = q.lo[1]; s_lo[2][k] = q.lo[2]; s_hi[0][k] = q.hi[0]; s_hi[1][k] = q.hi[1]; s_hi[2][k] = q.hi[2];
+        }
+    }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const int me = (int)threadIdx.x + radius;
+    const float lx = s_lo[0][me], ly = s_lo[1][me], lz = s_lo[2][me], hx = s_hi[0][me], hy = s_hi[1][me], hz = s_hi[2][me];
+    float best = INFINITY;
+    uint32_t best_j = i;
+    for (int d = -radius; d <= radius; d++) {
+        const int g = (int)i + d;
+        if (d == 0 || g < 0 || (uint32_t)g >= n) continue;
+        const int k = me + d;
+        const float dx = fmaxf(hx, s_hi[0][k]) - fminf(lx, s_lo[0][k]), dy = fmaxf(hy, s_hi[1][k]) - fminf(ly, s_lo[1][k]), dz = fmaxf(hz, s_hi[2][k]) - fminf(lz, s_lo[2][k]);
+        const float a = dx * dy + dy * dz + dz * dx;
+        bool better = a < best;
+        if (a == best) {                                    // pair order: (min, max) of (i, g) against (i, best_j)
+            const uint32_t m0 = min(i, (uint32_t)g), M0 = max(i, (uint32_t)g), m1 = min(i, best_j), M1 = max(i, best_j);
+            better = m0 < m1 || (m0 == m1 && M0 < M1);
+        }
+        if (better) { best = a; best_j = (uint32_t)g; }
+    }
+    nn[i] = best_j;
+}
+
+// mutual pairs merge into the lower slot (a new temporary node); the upper slot is dropped by the compaction
+__global__ __launch_bounds__(256) void k_ploc_merge(PlocCluster* __restrict__ c, const uint32_t* __restrict__ n_ptr, const uint32_t* __restrict__ nn,
+                                                    uint32_t* __restrict__ valid, int32_t* __restrict__ t_left, int32_t* __restrict__ t_right,
+                                                    uint32_t* __restrict__ t_count, uint32_t* __restrict__ counters) {
+    const uint32_t n = *n_ptr;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t j = nn[i];
+    const bool mutual = j != i && nn[j] == i;
+    if (!mutual) { valid[i] = 1u; return; }
+    if (i > j) { valid[i] = 0u; return; }
+    const PlocCluster a = c[i], b = c[j];
+    const uint32_t idx = atomicAdd(counters + 0, 1u);       // (the numbering is arbitrary: the layout pass renames every node)
+    t_left[idx] = a.ref; t_right[idx] = b.ref; t_count[idx] = a.count + b.count;
+    PlocCluster o;
+    for (int k = 0; k < 3; k++) { o.lo[k] = fminf(a.lo[k], b.lo[k]); o.hi[k] = fmaxf(a.hi[k], b.hi[k]); }
+    o.ref = (int32_t)idx; o.count = a.count + b.count;
+    c[i] = o;
+    valid[i] = 1u;
+}
+
+__global__ __launch_bounds__(256) void k_ploc_compact(const PlocCluster* __restrict__ in, const uint32_t* __restrict__ n_ptr, const uint32_t* __restrict__ valid,
+                                                      const uint32_t* __restrict__ pos, PlocCluster* __restrict__ out, uint32_t* __restrict__ n_out) {
+    const uint32_t n = *n_ptr;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (valid[i]) {
+        const float4* s4 = (const float4*)(in + i);
+        float4* d4 = (float4*)(out + pos[i]);
+        d4[0] = s4[0]; d4[1] = s4[1];
+    }
+    if (i == n - 1) *n_out = pos[i] + valid[i];
+}
+
+// layout, one level per launch: frontier entry = (temporary node, first leaf position, final index)
+__global__ __launch_bounds__(256) void k_ploc_layout_init(const PlocCluster* __restrict__ c, uint32_t* __restrict__ f_node, uint32_t* __restrict__ f_first,
+                                                          uint32_t* __restrict__ f_index, uint32_t* __restrict__ counters) {
+    for (int k = threadIdx.x; k < kCollapseMaxLevels; k += 256) counters[kPlocLevelBase + k] = k == 0 ? 1u : 0u;
+    if (threadIdx.x == 0) { f_node[0] = (uint32_t)c[0].ref; f_first[0] = 0u; f_index[0] = 0u; }
+}
+__global__ __launch_bounds__(256) void k_ploc_layout_level(const int32_t* __restrict__ t_left, const int32_t* __restrict__ t_right, const uint32_t* __restrict__ t_count,
+                                                           const uint32_t* __restrict__ f_node, const uint32_t* __restrict__ f_first, const uint32_t* __restrict__ f_index,
+                                                           uint32_t level, uint32_t* __restrict__ o_node, uint32_t* __restrict__ o_first, uint32_t* __restrict__ o_index,
+                                                           uint32_t* __restrict__ counters, BvhNode* __restrict__ nodes2, uint32_t* __restrict__ perm) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = i < counters[kPlocLevelBase + level];
+    int32_t l = -1, r = -1;
+    uint32_t first = 0, lc = 0;
+    if (active) {
+        const uint32_t t = f_node[i], me = f_index[i];
+        first = f_first[i];
+        l = t_left[t]; r = t_right[t];
+        const uint32_t cnt = t_count[t];
+        lc = l < 0 ? 1u : t_count[l];
+        BvhNode& n = nodes2[me];
+        n.child0 = l < 0 ? ~(int32_t)first : (int32_t)(first + lc - 1u);
+        n.child1 = r < 0 ? ~(int32_t)(first + lc) : (int32_t)(first + lc);
+        n._pad[0] = first; n._pad[1] = cnt;
+        if (l < 0) perm[first] = (uint32_t)~l;
+        if (r < 0) perm[first + lc] = (uint32_t)~r;
+    }
+    // inner children go to the next level's frontier: one atomic per wave and side
+    const uint32_t lane = __lane_id();
+    for (int side = 0; side < 2; side++) {
+        const bool push = active && (side == 0 ? l >= 0 : r >= 0);
+        const unsigned long long m = __ballot(push);
+        if (m == 0) continue;
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if ((int)lane == leader) base = atomicAdd(counters + kPlocLevelBase + level + 1, (uint32_t)__popcll(m));
+        base = __shfl(base, leader, 64);
+        if (push) {
+            const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            o_node[at] = (uint32_t)(side == 0 ? l : r);
+            o_first[at] = side == 0 ? first : first + lc;
+            o_index[at] = side == 0 ? first + lc - 1u : first + lc;
+        }
+    }
+}
+
+// triangle packets into the final (depth-first leaf) order
+__global__ __launch_bounds__(256) void k_ploc_gather(const TriPacket* __restrict__ in, const uint32_t* __restrict__ perm, uint32_t n, TriPacket* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4* s4 = (const float4*)(in + perm[i]);
+    float4* d4 = (float4*)(out + i);
+    d4[0] = s4[0]; d4[1] = s4[1]; d4[2] = s4[2];
+}
+
 static void free_all(AccelScratch& s) {
     hipFree(s.tris_unsorted); hipFree(s.keys_a); hipFree(s.keys_b); hipFree(s.vals_a); hipFree(s.vals_b);
     hipFree(s.leaf_parent); hipFree(s.node_parent); hipFree(s.seg); hipFree(s.block_bounds); hipFree(s.sort_temp);
     hipFree(s.nodes2); hipFree(s.kept); hipFree(s.widx); hipFree(s.collapse_counters); hipFree(s.wide_ranges);
+    hipFree(s.ploc_c[0]); hipFree(s.ploc_c[1]); hipFree(s.ploc_nn); hipFree(s.ploc_valid); hipFree(s.ploc_pos); hipFree(s.ploc_left); hipFree(s.ploc_right);
+    hipFree(s.ploc_count); hipFree(s.ploc_perm); hipFree(s.ploc_scan_temp); hipFree(s.ploc_counters);
 }
 
 static hipError_t ensure(AccelScratch& s, size_t n) {
     if (n <= s.capacity) return hipSuccess;
     free_all(s);
     uint32_t* bounds = s.bounds;
+    const int builder = s.builder;
     s = AccelScratch();
     s.bounds = bounds;
+    s.builder = builder;
     size_t cap = n + n / 8 + 64;
     hipError_t e;
     if ((e = hipMalloc(&s.tris_unsorted, cap * sizeof(TriPacket)))) return e;
@@ -503,6 +672,20 @@ static hipError_t ensure(AccelScratch& s, size_t n) {
     s.sort_temp_bytes = tb;
     if ((e = hipMalloc(&s.collapse_counters, (kCollapseMaxLevels + 16) * 4))) return e;
     if ((e = hipMalloc(&s.wide_ranges, cap * sizeof(WideRanges)))) return e;
+    // PLOC builder: two cluster arrays, partner / keep / position per cluster, the temporary tree, the final order
+    for (int k = 0; k < 2; k++) if ((e = hipMalloc(&s.ploc_c[k], cap * sizeof(PlocCluster)))) return e;
+    if ((e = hipMalloc(&s.ploc_nn, cap * 4))) return e;
+    if ((e = hipMalloc(&s.ploc_valid, cap * 4))) return e;
+    if ((e = hipMalloc(&s.ploc_pos, cap * 4))) return e;
+    if ((e = hipMalloc(&s.ploc_left, cap * 4))) return e;
+    if ((e = hipMalloc(&s.ploc_right, cap * 4))) return e;
+    if ((e = hipMalloc(&s.ploc_count, cap * 4))) return e;
+    if ((e = hipMalloc(&s.ploc_perm, cap * 4))) return e;
+    if ((e = hipMalloc(&s.ploc_counters, (kCollapseMaxLevels + 16) * 4))) return e;
+    size_t sb = 0;
+    if ((e = rocprim::exclusive_scan(nullptr, sb, s.ploc_valid, s.ploc_pos, 0u, cap, rocprim::plus<uint32_t>(), (hipStream_t)0))) return e;
+    if ((e = hipMalloc(&s.ploc_scan_temp, sb))) return e;
+    s.ploc_scan_bytes = sb;
     s.capacity = cap;
     return hipSuccess;
 }
@@ -510,7 +693,9 @@ static hipError_t ensure(AccelScratch& s, size_t n) {
 void accel_scratch_free(AccelScratch& s) {
     free_all(s);
     hipFree(s.bounds);
+    const int builder = s.builder;
     s = AccelScratch();
+    s.builder = builder;
 }
 
 // The segment tree over the sorted triangles' boxes (all levels), from the packets as they stand.
@@ -523,6 +708,62 @@ static void seg_build(AccelScratch& s, const TriPacket* d_tris, uint32_t n_tris,
         hipLaunchKernelGGL(k_seg_pass<false>, dim3((valid + 255) / 256), dim3(256), 0, stream, (const TriPacket*)nullptr, T, base, valid);
         valid = (valid + 255) / 256;
     }
+}
+
+// PLOC topology + layout: d_tris holds the Morton-sorted packets on entry and the packets in the tree's depth-first leaf order on
+// exit; s.nodes2 holds the binary tree in the same form k_hierarchy leaves it (children, range; boxes come from k_fit).
+static hipError_t ploc_build(AccelScratch& s, uint32_t n_tris, TriPacket* d_tris, hipStream_t stream) {
+    hipError_t e;
+    PlocCluster* c[2] = {(PlocCluster*)s.ploc_c[0], (PlocCluster*)s.ploc_c[1]};
+    uint32_t* cnt = s.ploc_counters;
+    hipLaunchKernelGGL(k_ploc_init, dim3((n_tris + 255) / 256), dim3(256), 0, stream, (const TriPacket*)d_tris, n_tris, c[0], cnt);
+    uint32_t bound = n_tris;
+    int round = 0;
+    for (;;) {
+        if (round > 4096) return hipErrorUnknown;                    // every round merges at least the globally best pair; guards a hang
+        for (int k = 0; k < 4; k++, round++) {                       // four rounds per look at the count
+            const int a = round & 1;
+            const dim3 grid((bound + 255) / 256);
+            hipLaunchKernelGGL(k_ploc_nearest, grid, dim3(256), 0, stream, (const PlocCluster*)c[a], (const uint32_t*)(cnt + 4 + a), s.ploc_nn);
+            hipLaunchKernelGGL(k_ploc_merge, grid, dim3(256), 0, stream, c[a], (const uint32_t*)(cnt + 4 + a), (const uint32_t*)s.ploc_nn, s.ploc_valid, s.ploc_left,
+                               s.ploc_right, s.ploc_count, cnt);
+            size_t sb = s.ploc_scan_bytes;
+            if ((e = rocprim::exclusive_scan(s.ploc_scan_temp, sb, s.ploc_valid, s.ploc_pos, 0u, (size_t)bound, rocprim::plus<uint32_t>(), stream))) return e;
+            hipLaunchKernelGGL(k_ploc_compact, grid, dim3(256), 0, stream, (const PlocCluster*)c[a], (const uint32_t*)(cnt + 4 + a), (const uint32_t*)s.ploc_valid,
+                               (const uint32_t*)s.ploc_pos, c[a ^ 1], cnt + 4 + (a ^ 1));
+        }
+        uint32_t n_cur = 0;
+        if ((e = hipMemcpyAsync(&n_cur, cnt + 4 + (round & 1), 4, hipMemcpyDeviceToHost, stream))) return e;
+        if ((e = hipStreamSynchronize(stream))) return e;
+        if (n_cur == 0 || n_cur > bound) return hipErrorUnknown;
+        if (n_cur == 1) break;
+        bound = n_cur;
+    }
+    // layout: ranges, final indices, final triangle order
+    uint32_t* fn[2] = {s.kept, s.vals_a};
+    uint32_t* ff[2] = {s.widx, s.vals_b};
+    uint32_t* fi[2] = {(uint32_t*)s.leaf_parent, (uint32_t*)s.node_parent};
+    hipLaunchKernelGGL(k_ploc_layout_init, dim3(1), dim3(256), 0, stream, (const PlocCluster*)c[round & 1], fn[0], ff[0], fi[0], cnt);
+    uint32_t fb = 1;
+    const uint32_t n_nodes = n_tris - 1;
+    for (uint32_t level = 0, cur = 0;;) {
+        if (level + 8 >= (uint32_t)kCollapseMaxLevels) return hipErrorUnknown;
+        for (int j = 0; j < 8; j++, level++, cur ^= 1u) {
+            hipLaunchKernelGGL(k_ploc_layout_level, dim3((fb + 255) / 256), dim3(256), 0, stream, (const int32_t*)s.ploc_left, (const int32_t*)s.ploc_right,
+                               (const uint32_t*)s.ploc_count, (const uint32_t*)fn[cur], (const uint32_t*)ff[cur], (const uint32_t*)fi[cur], level, fn[cur ^ 1u], ff[cur ^ 1u],
+                               fi[cur ^ 1u], cnt, s.nodes2, s.ploc_perm);
+            fb = fb > n_nodes / 2 ? n_nodes : fb * 2;
+        }
+        uint32_t next = 0;
+        if ((e = hipMemcpyAsync(&next, cnt + kPlocLevelBase + level, 4, hipMemcpyDeviceToHost, stream))) return e;
+        if ((e = hipStreamSynchronize(stream))) return e;
+        if (next > n_nodes) return hipErrorUnknown;
+        if (next == 0) break;
+        fb = next;
+    }
+    hipLaunchKernelGGL(k_ploc_gather, dim3((n_tris + 255) / 256), dim3(256), 0, stream, (const TriPacket*)d_tris, (const uint32_t*)s.ploc_perm, n_tris, s.tris_unsorted);
+    if ((e = hipMemcpyAsync(d_tris, s.tris_unsorted, (size_t)n_tris * sizeof(TriPacket), hipMemcpyDeviceToDevice, stream))) return e;
+    return hipGetLastError();
 }
 
 hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const InstanceRec* d_instances, int n_inst, uint32_t n_tris, Bvh4Node* d_nodes,
@@ -546,8 +787,9 @@ hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const Instan
     size_t tb = s.sort_temp_bytes;
     if ((e = rocprim::radix_sort_pairs(s.sort_temp, tb, s.keys_a, s.keys_b, s.vals_a, s.vals_b, (size_t)n_tris, 0, 63, stream))) return e;
     hipLaunchKernelGGL(k_reorder, dim3(g), dim3(256), 0, stream, s.tris_unsorted, s.vals_b, n_tris, d_tris);
+    if (s.builder == 1) { if ((e = ploc_build(s, n_tris, d_tris, stream))) return e; }
+    else hipLaunchKernelGGL(k_hierarchy, dim3(g), dim3(256), 0, stream, s.keys_b, (int)n_tris, s.nodes2, s.node_parent, s.leaf_parent);
     hipLaunchKernelGGL(k_shade_packets, dim3(g), dim3(256), 0, stream, d_tris, n_tris, d_instances, d_shade);
-    hipLaunchKernelGGL(k_hierarchy, dim3(g), dim3(256), 0, stream, s.keys_b, (int)n_tris, s.nodes2, s.node_parent, s.leaf_parent);
     const uint32_t n_nodes = n_tris - 1;
     seg_build(s, d_tris, n_tris, stream);
     hipLaunchKernelGGL(k_fit, dim3((n_nodes + 255) / 256), dim3(256), 0, stream, (const SegBox*)s.seg, (uint32_t)s.seg_leaves, n_nodes, s.nodes2);

@@ -12,6 +12,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -525,6 +526,10 @@ int pt_create(int device, void* hip_stream, const float* sheen_e_16x16, pt_ctx**
     ok = ok && hipEventCreateWithFlags(&ctx->bones_fence, hipEventDisableTiming) == hipSuccess;
     if (!ok) { pt_destroy(ctx); return PT_ERR_DEVICE; }
     ctx->samplers.push_back({PT_ADDRESS_WRAP, PT_ADDRESS_WRAP, PT_FILTER_LINEAR, PT_FILTER_LINEAR});   // sampler 0 (GpuResources.cpp:47-59)
+    if (const char* b = getenv("MIPT_ACCEL_BUILDER")) {      // initial builder of new contexts (pt_set_accel_builder overrides): "lbvh" | "ploc"
+        if (!strcmp(b, "ploc")) ctx->scratch.builder = PT_BUILDER_PLOC;
+        else if (!strcmp(b, "lbvh")) ctx->scratch.builder = PT_BUILDER_LBVH;
+    }
     *out = ctx;
     return PT_OK;
 }
@@ -864,6 +869,12 @@ int pt_build_accel(pt_ctx* ctx) {
 int pt_accel_request_rebuild(pt_ctx* ctx) {
     if (!ctx) return PT_ERR_INVALID_ARGUMENT;
     ctx->accel_state = ACCEL_REBUILD;
+    return PT_OK;
+}
+
+int pt_set_accel_builder(pt_ctx* ctx, int builder) {
+    if (!ctx || (builder != PT_BUILDER_LBVH && builder != PT_BUILDER_PLOC)) return PT_ERR_INVALID_ARGUMENT;
+    if (ctx->scratch.builder != builder) { ctx->scratch.builder = builder; ctx->accel_state = ACCEL_REBUILD; }
     return PT_OK;
 }
 

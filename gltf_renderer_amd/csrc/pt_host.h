@@ -27,6 +27,12 @@ struct AccelScratch {
     uint32_t* widx = nullptr;        // ... and the wide-node index each was given
     uint32_t* collapse_counters = nullptr;   // greedy collapse: [0] wide nodes allocated, [1 + L] frontier size of level L
     WideRanges* wide_ranges = nullptr;       // per wide node: the sorted-triangle range under each child (kept for accel_refit)
+    // PLOC builder (accel.hip 4b)
+    int builder = 1;                         // PT_BUILDER_*: 0 radix tree (Karras LBVH); 1 PLOC clustering over the same Morton order (default)
+    void* ploc_c[2] = {nullptr, nullptr};    // cluster arrays (ping-pong)
+    uint32_t *ploc_nn = nullptr, *ploc_valid = nullptr, *ploc_pos = nullptr, *ploc_count = nullptr, *ploc_perm = nullptr, *ploc_counters = nullptr;
+    int32_t *ploc_left = nullptr, *ploc_right = nullptr;
+    void* ploc_scan_temp = nullptr; size_t ploc_scan_bytes = 0;
     size_t capacity = 0;
 };
 void accel_scratch_free(AccelScratch& s);

@@ -21,7 +21,7 @@ EXPORTS = ["pt_abi_version", "pt_create", "pt_destroy", "pt_last_error", "pt_buf
            "pt_set_kernel_mode",
            "pt_get_stats", "pt_reset_stats", "pt_readback", "pt_tonemap",
            # ABI 2
-           "pt_buffer_destroy", "pt_texture_destroy", "pt_env_destroy", "pt_accel_request_rebuild", "pt_enable_stage_timing",
+           "pt_buffer_destroy", "pt_texture_destroy", "pt_env_destroy", "pt_accel_request_rebuild", "pt_set_accel_builder", "pt_enable_stage_timing",
            "pt_exchange_unique_id", "pt_exchange_create", "pt_exchange_frame", "pt_exchange_destroy",
            "pt_tiles_packed_bytes", "pt_tiles_pack", "pt_tiles_unpack"]
 
@@ -81,6 +81,7 @@ def load_library():
     L.pt_texture_destroy.argtypes = [vp, ci]
     L.pt_env_destroy.argtypes = [vp, ci]
     L.pt_accel_request_rebuild.argtypes = [vp]
+    L.pt_set_accel_builder.argtypes = [vp, ci]
     L.pt_enable_stage_timing.argtypes = [vp, ci]
     L.pt_exchange_unique_id.argtypes = [vp]
     L.pt_exchange_create.argtypes = [vp, ci, ci, vp]
@@ -233,6 +234,10 @@ class Renderer:
 
     def request_rebuild(self):
         self._check(self.L.pt_accel_request_rebuild(self.h))
+
+    def set_accel_builder(self, builder):
+        """abi.BUILDER_LBVH (radix tree) or abi.BUILDER_PLOC (clustering by surface area: better tree, slower build)."""
+        self._check(self.L.pt_set_accel_builder(self.h, int(builder)))
 
     def enable_stage_timing(self, on):
         self._check(self.L.pt_enable_stage_timing(self.h, int(bool(on))))
