@@ -483,6 +483,12 @@ __global__ __launch_bounds__(1024) void k_collapse_small(const BvhNode* __restri
 #define PT_PLOC_RADIUS 8        // neighbours looked at on either side while the array is long (measured 8 / 16 / 32 / 64 / 128 on the Sponza-class
                                 // scene: 4820 / 4749 / 4744 / 4761 / 4619 Mrays/s at 8 spp)
 #endif
+#ifndef PT_PLOC_TIE
+#define PT_PLOC_TIE 4      // order among partners of EQUAL joint area (regular grids are full of them); Mrays/s at 8 spp, Sponza class / material grid:
+                        // 0 (index distance, parity, lower index) 4750 / 3030; 1 (parity first) 4739 / 3027; 3 (farthest first) 4856 / 2923, unsafe;
+                        // 2 (lower index only) 4840 / 3021, unsafe: a strip of equal quads merges ONE pair per round; 4 (the more compact union, then 0)
+                        // 4813 / 3029 -- safe and near the best on both
+#endif
 #ifndef PT_PLOC_RADIUS_TOP
 #define PT_PLOC_RADIUS_TOP 8    // ... and once fewer than kPlocTopClusters clusters are left (the upper levels of the tree)
 #endif
@@ -506,8 +512,8 @@ __global__ __launch_bounds__(256) void k_ploc_init(const TriPacket* __restrict__
     c[i] = o;
 }
 
-// the partner with the smallest joint surface area among the 2 * kPlocRadius neighbours; ties go to the lexicographically
-// smaller (min index, max index) pair, a strict total order on pairs, so the globally best pair always chooses each other
+// the partner with the smallest joint surface area among the 2 * radius neighbours; ties are broken by a strict total order on
+// pairs (below), so the globally best pair always chooses each other and every round merges at least one pair
 __global__ __launch_bounds__(256) void k_ploc_nearest(const PlocCluster* __restrict__ c, const uint32_t* __restrict__ n_ptr, uint32_t* __restrict__ nn) {
     __shared__ float s_lo[3][256 + 2 * kPlocRadiusMax], s_hi[3][256 + 2 * kPlocRadiusMax];
     const uint32_t n = *n_ptr;
@@ -526,20 +532,46 @@ __global__ __launch_bounds__(256) void k_ploc_nearest(const PlocCluster* __restr
     if (i >= n) return;
     const int me = (int)threadIdx.x + radius;
     const float lx = s_lo[0][me], ly = s_lo[1][me], lz = s_lo[2][me], hx = s_hi[0][me], hy = s_hi[1][me], hz = s_hi[2][me];
-    float best = INFINITY;
+    float best = INFINITY, best_e = INFINITY;
     uint32_t best_j = i;
     for (int d = -radius; d <= radius; d++) {
         const int g = (int)i + d;
         if (d == 0 || g < 0 || (uint32_t)g >= n) continue;
         const int k = me + d;
         const float dx = fmaxf(hx, s_hi[0][k]) - fminf(lx, s_lo[0][k]), dy = fmaxf(hy, s_hi[1][k]) - fminf(ly, s_lo[1][k]), dz = fmaxf(hz, s_hi[2][k]) - fminf(lz, s_lo[2][k]);
-        const float a = dx * dy + dy * dz + dz * dx;
+        float a = dx * dy + dy * dz + dz * dx;
+        a = (a == a) ? fminf(a, 3.0e38f) : 3.0e38f;          // NaN or overflowing boxes (garbage vertices) still pair up, by index: the rounds always end
+#if PT_PLOC_TIE == 4
+        // equal areas: the more compact union first (a 2 x 2 block of quads and a 4 x 1 strip have the same area; the block is the
+        // better node), then the index rule below
+        float e = dx + dy + dz;
+        e = (e == e) ? fminf(e, 3.0e38f) : 3.0e38f;
+        bool better = a < best || (a == best && best_j != i && e < best_e);
+        const bool tie = a == best && best_j != i && e == best_e;
+#else
+        const float e = 0.0f;
         bool better = a < best;
-        if (a == best) {                                    // pair order: (min, max) of (i, g) against (i, best_j)
-            const uint32_t m0 = min(i, (uint32_t)g), M0 = max(i, (uint32_t)g), m1 = min(i, best_j), M1 = max(i, best_j);
+        const bool tie = a == best && best_j != i;
+#endif
+        if (tie) {
+            // equal areas (coincident triangles, regular grids): a strict total order on PAIRS -- (index distance, parity of the lower
+            // index, lower index) -- so that the globally best pair still chooses each other, and chosen so that in a run of equal
+            // boxes 0-1, 2-3, 4-5 ... pair up in ONE round (ordering by the lower index alone chains everybody to the left
+            // neighbour and merges one pair per round)
+            const uint32_t d0 = (uint32_t)(d < 0 ? -d : d), d1 = best_j > i ? best_j - i : i - best_j;
+            const uint32_t m0 = min(i, (uint32_t)g), m1 = min(i, best_j);
+#if PT_PLOC_TIE == 1       // parity of the lower index first, then distance
+            better = (m0 & 1u) < (m1 & 1u) || ((m0 & 1u) == (m1 & 1u) && (d0 < d1 || (d0 == d1 && m0 < m1)));
+#elif PT_PLOC_TIE == 2     // lexicographic (min, max): chains in runs of equal boxes (one merge per round) -- measurement only
+            const uint32_t M0 = max(i, (uint32_t)g), M1 = max(i, best_j);
             better = m0 < m1 || (m0 == m1 && M0 < M1);
+#elif PT_PLOC_TIE == 3     // farthest first, then parity
+            better = d0 > d1 || (d0 == d1 && ((m0 & 1u) < (m1 & 1u) || ((m0 & 1u) == (m1 & 1u) && m0 < m1)));
+#else
+            better = d0 < d1 || (d0 == d1 && ((m0 & 1u) < (m1 & 1u) || ((m0 & 1u) == (m1 & 1u) && m0 < m1)));
+#endif
         }
-        if (better) { best = a; best_j = (uint32_t)g; }
+        if (better) { best = a; best_e = e; best_j = (uint32_t)g; }
     }
     nn[i] = best_j;
 }

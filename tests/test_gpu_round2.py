@@ -155,6 +155,51 @@ def test_builders_agree_and_ploc_visits_fewer_nodes(R):
     assert per_ray["ploc"] < 0.9 * per_ray["lbvh"]
 
 
+def test_coincident_and_garbage_triangles_build_or_fail_loudly(R):
+    """Thousands of triangles with one centroid give every Morton code the same value: the radix tree degenerates into a chain that
+    no traversal stack can serve -- the build must refuse it (PT_ERR_CAPACITY), never drop geometry silently -- while PLOC pairs
+    equal boxes by index and stays balanced.  A mesh with NaN / huge vertices must not hang either builder."""
+    from gltf_renderer_amd.renderer import MiptError
+    base = scenes.single_triangle(64)
+    tri = np.array([[-1, 0, -1], [1, 0, -1], [0, 0, 1]], f32)
+    n = 6000
+    pos = np.tile(tri, (n, 1))
+    many = meshgen.Mesh(pos, np.arange(3 * n), normals=np.tile(np.array([[0, -1, 0]], f32), (3 * n, 1)), uv0=np.tile(np.array([[0, 1], [1, 1], [0.5, 0]], f32), (n, 1)))
+    ref_r = R(); ref_h = base.upload(ref_r)
+    ref = debug_image(ref_r, base, ref_h, abi.DEBUG_OUTPUT_HIT_KIND)
+    ref_r.close()
+    s = scenes.single_triangle(64)
+    s.instances.clear(); s.mesh_records.clear(); s.buffers.clear(); s.triangles = 0
+    s.add_mesh(many, None, 0)
+    r = R(); r.set_accel_builder(abi.BUILDER_PLOC); h = s.upload(r)
+    img = debug_image(r, s, h, abi.DEBUG_OUTPUT_HIT_KIND)
+    q = r.stats()
+    assert q.bvh_triangles == n and q.bvh_stack_need <= 64
+    assert np.array_equal(img, ref)                             # the same silhouette, whichever copy is hit
+    r.set_accel_builder(abi.BUILDER_LBVH)
+    try:
+        img2 = debug_image(r, s, h, abi.DEBUG_OUTPUT_HIT_KIND)
+        assert np.array_equal(img2, ref) and r.stats().bvh_stack_need <= 64
+    except MiptError as e:
+        assert "traversal stack" in str(e)
+    r.close()
+    # garbage vertices: NaN and 1e30 among ordinary ones
+    bad = pos[: 3 * 300].copy()
+    bad += np.random.default_rng(5).normal(0, 0.3, bad.shape).astype(f32)
+    bad[7] = np.nan; bad[100] = 1e30; bad[203, 1] = -np.inf
+    s2 = scenes.single_triangle(32)
+    s2.instances.clear(); s2.mesh_records.clear(); s2.buffers.clear(); s2.triangles = 0
+    s2.add_mesh(meshgen.Mesh(bad, np.arange(900), normals=np.tile(np.array([[0, -1, 0]], f32), (900, 1))), None, 0)
+    for b in (abi.BUILDER_PLOC, abi.BUILDER_LBVH):
+        r = R(); r.set_accel_builder(b); h = s2.upload(r)
+        try:
+            out = debug_image(r, s2, h, abi.DEBUG_OUTPUT_HIT_KIND)
+            assert out.shape == (32, 32, 4)
+        except MiptError:
+            pass                                                # refusing garbage is fine; hanging or faulting is not
+        r.close()
+
+
 def test_refit_of_the_figure_scene_matches_the_oracle(R, oracle_lib):
     """config-5 class: build at pose A, refit to pose B, render; the oracle (which always rebuilds) at pose B must agree."""
     import oracle.pyoracle as po
