@@ -12,7 +12,12 @@
 //                  of them, so its box is one O(log count) range query -- no inter-lane hand-over, no fences
 // Every stage streams its arrays once (HBM-bound; 48 B + 8 B + 64 B per triangle).
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <string>
+#include <algorithm>
+#include <vector>
 #include <rocprim/rocprim.hpp>
 
 #include "pt_math.h"
@@ -483,12 +488,9 @@ __global__ __launch_bounds__(1024) void k_collapse_small(const BvhNode* __restri
 #define PT_PLOC_RADIUS 8        // neighbours looked at on either side while the array is long (measured 8 / 16 / 32 / 64 / 128 on the Sponza-class
                                 // scene: 4820 / 4749 / 4744 / 4761 / 4619 Mrays/s at 8 spp)
 #endif
-#ifndef PT_PLOC_TIE
-#define PT_PLOC_TIE 4      // order among partners of EQUAL joint area (regular grids are full of them); Mrays/s at 8 spp, Sponza class / material grid:
-                        // 0 (index distance, parity, lower index) 4750 / 3030; 1 (parity first) 4739 / 3027; 3 (farthest first) 4856 / 2923, unsafe;
-                        // 2 (lower index only) 4840 / 3021, unsafe: a strip of equal quads merges ONE pair per round; 4 (the more compact union, then 0)
-                        // 4813 / 3029 -- safe and near the best on both
-#endif
+// (Order among partners of equal joint area, Mrays/s at 8 spp on the Sponza-class scene / the material grid: index distance then parity
+//  4750 / 3030; parity first 4739 / 3027; farthest first 4856 / 2923 and lower index only 4840 / 3021, both unsafe -- a strip of equal
+//  quads merges one pair per round; the more compact union first, then index distance and parity: 4813 / 3029 -- what k_ploc_nearest does.)
 #ifndef PT_PLOC_RADIUS_TOP
 #define PT_PLOC_RADIUS_TOP 8    // ... and once fewer than kPlocTopClusters clusters are left (the upper levels of the tree)
 #endif
@@ -512,8 +514,16 @@ __global__ __launch_bounds__(256) void k_ploc_init(const TriPacket* __restrict__
     c[i] = o;
 }
 
-// the partner with the smallest joint surface area among the 2 * radius neighbours; ties are broken by a strict total order on
-// pairs (below), so the globally best pair always chooses each other and every round merges at least one pair
+// the partner with the smallest joint surface area among the 2 * radius neighbours.  A pair is ranked by an INTEGER key that is the
+// same from both of its ends -- (area bits, extent-sum bits | index distance, parity of the lower index, lower index) -- a strict
+// total order on pairs, so the globally best pair always chooses each other and every round merges at least one pair.  The order
+// among equal areas (regular grids are full of them) matters twice: for the tree -- the more compact union first: a 2 x 2 block of
+// quads and a 4 x 1 strip have the same area, the block is the better node -- and for the number of rounds -- index distance, then
+// the parity of the lower index, make a run of equal boxes pair up 0-1, 2-3, 4-5 ... in ONE round, where "lower index first" chains
+// every cluster to its left neighbour and merges one pair per round.  (The ranking was first written as chained float comparisons
+// `a < best || (a == best && ...)`; that version stalled on a real scene -- clusters choosing i - 3 over an i - 1 with the
+// bit-identical union box, nobody chosen back -- and converged again when unrelated stores were added to the loop: the integer
+// key leaves the compiler nothing to reorder.)
 __global__ __launch_bounds__(256) void k_ploc_nearest(const PlocCluster* __restrict__ c, const uint32_t* __restrict__ n_ptr, uint32_t* __restrict__ nn) {
     __shared__ float s_lo[3][256 + 2 * kPlocRadiusMax], s_hi[3][256 + 2 * kPlocRadiusMax];
     const uint32_t n = *n_ptr;
@@ -522,56 +532,32 @@ __global__ __launch_bounds__(256) void k_ploc_nearest(const PlocCluster* __restr
     if ((uint32_t)(blockIdx.x * 256u) >= n) return;
     for (int k = threadIdx.x; k < 256 + 2 * radius; k += 256) {
         const int g = base + k;
-        if (g >= 0 && (uint32_t)g < n) {
-            const PlocCluster& q = c[g];
-            s_lo[0][k] = q.lo[0]; s_lo[1][k] = q.lo[1]; s_lo[2][k] = q.lo[2]; s_hi[0][k] = q.hi[0]; s_hi[1][k] = q.hi[1]; s_hi[2][k] = q.hi[2];
-        }
+        const bool in = g >= 0 && (uint32_t)g < n;
+        const PlocCluster& q = c[in ? g : 0];
+        s_lo[0][k] = in ? q.lo[0] : 0.f; s_lo[1][k] = in ? q.lo[1] : 0.f; s_lo[2][k] = in ? q.lo[2] : 0.f;
+        s_hi[0][k] = in ? q.hi[0] : 0.f; s_hi[1][k] = in ? q.hi[1] : 0.f; s_hi[2][k] = in ? q.hi[2] : 0.f;
     }
     __syncthreads();
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const int me = (int)threadIdx.x + radius;
     const float lx = s_lo[0][me], ly = s_lo[1][me], lz = s_lo[2][me], hx = s_hi[0][me], hy = s_hi[1][me], hz = s_hi[2][me];
-    float best = INFINITY, best_e = INFINITY;
+    unsigned long long best_hi = ~0ull, best_lo = ~0ull;
     uint32_t best_j = i;
     for (int d = -radius; d <= radius; d++) {
         const int g = (int)i + d;
         if (d == 0 || g < 0 || (uint32_t)g >= n) continue;
         const int k = me + d;
         const float dx = fmaxf(hx, s_hi[0][k]) - fminf(lx, s_lo[0][k]), dy = fmaxf(hy, s_hi[1][k]) - fminf(ly, s_lo[1][k]), dz = fmaxf(hz, s_hi[2][k]) - fminf(lz, s_lo[2][k]);
-        float a = dx * dy + dy * dz + dz * dx;
-        a = (a == a) ? fminf(a, 3.0e38f) : 3.0e38f;          // NaN or overflowing boxes (garbage vertices) still pair up, by index: the rounds always end
-#if PT_PLOC_TIE == 4
-        // equal areas: the more compact union first (a 2 x 2 block of quads and a 4 x 1 strip have the same area; the block is the
-        // better node), then the index rule below
-        float e = dx + dy + dz;
-        e = (e == e) ? fminf(e, 3.0e38f) : 3.0e38f;
-        bool better = a < best || (a == best && best_j != i && e < best_e);
-        const bool tie = a == best && best_j != i && e == best_e;
-#else
-        const float e = 0.0f;
-        bool better = a < best;
-        const bool tie = a == best && best_j != i;
-#endif
-        if (tie) {
-            // equal areas (coincident triangles, regular grids): a strict total order on PAIRS -- (index distance, parity of the lower
-            // index, lower index) -- so that the globally best pair still chooses each other, and chosen so that in a run of equal
-            // boxes 0-1, 2-3, 4-5 ... pair up in ONE round (ordering by the lower index alone chains everybody to the left
-            // neighbour and merges one pair per round)
-            const uint32_t d0 = (uint32_t)(d < 0 ? -d : d), d1 = best_j > i ? best_j - i : i - best_j;
-            const uint32_t m0 = min(i, (uint32_t)g), m1 = min(i, best_j);
-#if PT_PLOC_TIE == 1       // parity of the lower index first, then distance
-            better = (m0 & 1u) < (m1 & 1u) || ((m0 & 1u) == (m1 & 1u) && (d0 < d1 || (d0 == d1 && m0 < m1)));
-#elif PT_PLOC_TIE == 2     // lexicographic (min, max): chains in runs of equal boxes (one merge per round) -- measurement only
-            const uint32_t M0 = max(i, (uint32_t)g), M1 = max(i, best_j);
-            better = m0 < m1 || (m0 == m1 && M0 < M1);
-#elif PT_PLOC_TIE == 3     // farthest first, then parity
-            better = d0 > d1 || (d0 == d1 && ((m0 & 1u) < (m1 & 1u) || ((m0 & 1u) == (m1 & 1u) && m0 < m1)));
-#else
-            better = d0 < d1 || (d0 == d1 && ((m0 & 1u) < (m1 & 1u) || ((m0 & 1u) == (m1 & 1u) && m0 < m1)));
-#endif
-        }
-        if (better) { best = a; best_e = e; best_j = (uint32_t)g; }
+        float a = __fadd_rn(__fadd_rn(__fmul_rn(dx, dy), __fmul_rn(dy, dz)), __fmul_rn(dz, dx));      // explicitly rounded: the same bits from both ends
+        float e = __fadd_rn(__fadd_rn(dx, dy), dz);
+        // NaN, negative or overflowing values (garbage vertices) rank last but still pair up, by index: the rounds always end
+        a = (a >= 0.0f) ? fminf(a, 3.0e38f) : 3.0e38f;
+        e = (e >= 0.0f) ? fminf(e, 3.0e38f) : 3.0e38f;
+        const uint32_t dist = (uint32_t)(d < 0 ? -d : d), m = min(i, (uint32_t)g);
+        const unsigned long long key_hi = ((unsigned long long)__float_as_uint(a) << 32) | (unsigned long long)__float_as_uint(e);   // non-negative floats order like their bits
+        const unsigned long long key_lo = ((unsigned long long)dist << 33) | ((unsigned long long)(m & 1u) << 32) | (unsigned long long)m;
+        if (key_hi < best_hi || (key_hi == best_hi && key_lo < best_lo)) { best_hi = key_hi; best_lo = key_lo; best_j = (uint32_t)g; }
     }
     nn[i] = best_j;
 }
@@ -752,7 +738,7 @@ static hipError_t ploc_build(AccelScratch& s, uint32_t n_tris, TriPacket* d_tris
     uint32_t bound = n_tris;
     int round = 0;
     for (;;) {
-        if (round > 4096) return hipErrorUnknown;                    // every round merges at least the globally best pair; guards a hang
+        if (round > 4096) { s.why = "PLOC: more than 4096 clustering rounds"; return hipErrorUnknown; }   // every round merges at least the globally best pair; guards a hang
         for (int k = 0; k < 4; k++, round++) {                       // four rounds per look at the count
             const int a = round & 1;
             const dim3 grid((bound + 255) / 256);
@@ -767,7 +753,9 @@ static hipError_t ploc_build(AccelScratch& s, uint32_t n_tris, TriPacket* d_tris
         uint32_t n_cur = 0;
         if ((e = hipMemcpyAsync(&n_cur, cnt + 4 + (round & 1), 4, hipMemcpyDeviceToHost, stream))) return e;
         if ((e = hipStreamSynchronize(stream))) return e;
-        if (n_cur == 0 || n_cur > bound) return hipErrorUnknown;
+        if (n_cur == bound && n_cur > 1) { s.why = "PLOC: no pair merged in four rounds at " + std::to_string(n_cur) + " clusters"; return hipErrorNotReady; }
+        if (n_cur == 0 || n_cur > bound) { s.why = "PLOC: cluster count " + std::to_string(n_cur) + " after round " + std::to_string(round) + " (bound " + std::to_string(bound) + ")"; return hipErrorUnknown; }
+        if (getenv("MIPT_DEBUG_PLOC")) fprintf(stderr, "PLOC round %d: %u clusters\n", round, n_cur);
         if (n_cur == 1) break;
         bound = n_cur;
     }
@@ -779,7 +767,7 @@ static hipError_t ploc_build(AccelScratch& s, uint32_t n_tris, TriPacket* d_tris
     uint32_t fb = 1;
     const uint32_t n_nodes = n_tris - 1;
     for (uint32_t level = 0, cur = 0;;) {
-        if (level + 8 >= (uint32_t)kCollapseMaxLevels) return hipErrorUnknown;
+        if (level + 8 >= (uint32_t)kCollapseMaxLevels) { s.why = "PLOC: tree deeper than " + std::to_string(kCollapseMaxLevels) + " levels"; return hipErrorUnknown; }
         for (int j = 0; j < 8; j++, level++, cur ^= 1u) {
             hipLaunchKernelGGL(k_ploc_layout_level, dim3((fb + 255) / 256), dim3(256), 0, stream, (const int32_t*)s.ploc_left, (const int32_t*)s.ploc_right,
                                (const uint32_t*)s.ploc_count, (const uint32_t*)fn[cur], (const uint32_t*)ff[cur], (const uint32_t*)fi[cur], level, fn[cur ^ 1u], ff[cur ^ 1u],
@@ -789,7 +777,7 @@ static hipError_t ploc_build(AccelScratch& s, uint32_t n_tris, TriPacket* d_tris
         uint32_t next = 0;
         if ((e = hipMemcpyAsync(&next, cnt + kPlocLevelBase + level, 4, hipMemcpyDeviceToHost, stream))) return e;
         if ((e = hipStreamSynchronize(stream))) return e;
-        if (next > n_nodes) return hipErrorUnknown;
+        if (next > n_nodes) { s.why = "PLOC: layout frontier of " + std::to_string(next) + " entries at level " + std::to_string(level); return hipErrorUnknown; }
         if (next == 0) break;
         fb = next;
     }
@@ -819,8 +807,15 @@ hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const Instan
     size_t tb = s.sort_temp_bytes;
     if ((e = rocprim::radix_sort_pairs(s.sort_temp, tb, s.keys_a, s.keys_b, s.vals_a, s.vals_b, (size_t)n_tris, 0, 63, stream))) return e;
     hipLaunchKernelGGL(k_reorder, dim3(g), dim3(256), 0, stream, s.tris_unsorted, s.vals_b, n_tris, d_tris);
-    if (s.builder == 1) { if ((e = ploc_build(s, n_tris, d_tris, stream))) return e; }
-    else hipLaunchKernelGGL(k_hierarchy, dim3(g), dim3(256), 0, stream, s.keys_b, (int)n_tris, s.nodes2, s.node_parent, s.leaf_parent);
+    bool radix = s.builder != 1;
+    if (!radix) {
+        e = ploc_build(s, n_tris, d_tris, stream);
+        // the clustering must merge at least its globally best pair every round; if it ever does not (inconsistent arithmetic), the
+        // radix tree over the same, still untouched Morton order takes over rather than the build failing
+        if (e == hipErrorNotReady) { radix = true; (void)hipGetLastError(); }
+        else if (e) return e;
+    }
+    if (radix) hipLaunchKernelGGL(k_hierarchy, dim3(g), dim3(256), 0, stream, s.keys_b, (int)n_tris, s.nodes2, s.node_parent, s.leaf_parent);
     hipLaunchKernelGGL(k_shade_packets, dim3(g), dim3(256), 0, stream, d_tris, n_tris, d_instances, d_shade);
     const uint32_t n_nodes = n_tris - 1;
     seg_build(s, d_tris, n_tris, stream);
@@ -846,7 +841,7 @@ hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const Instan
     // at most every node); the kernels read the true sizes from the device, the host looks once per eight levels.
     uint32_t bound = 1;
     for (uint32_t level = 0, cur = 0;;) {
-        if (level >= (uint32_t)kCollapseMaxLevels) return hipErrorUnknown;   // far deeper than a 64-bit radix tree can be; guards a hang
+        if (level >= (uint32_t)kCollapseMaxLevels) { s.why = "collapse: more than " + std::to_string(kCollapseMaxLevels) + " levels"; return hipErrorUnknown; }   // guards a hang
         for (int j = 0; j < 8; j++, level++, cur ^= 1u) {
             hipLaunchKernelGGL(k_collapse_level, dim3((bound + 255) / 256), dim3(256), 0, stream, s.nodes2, fr[cur], wi[cur], level, fr[cur ^ 1u], wi[cur ^ 1u],
                                s.collapse_counters, d_nodes, s.wide_ranges, nd[cur], nd[cur ^ 1u]);
@@ -856,7 +851,7 @@ hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const Instan
         if ((e = hipMemcpyAsync(&next, s.collapse_counters + 1 + level, 4, hipMemcpyDeviceToHost, stream))) return e;
         if ((e = hipMemcpyAsync(wide_nodes_out, s.collapse_counters, 4, hipMemcpyDeviceToHost, stream))) return e;
         if ((e = hipStreamSynchronize(stream))) return e;
-        if (next > n_nodes) return hipErrorUnknown;
+        if (next > n_nodes) { s.why = "collapse: frontier of " + std::to_string(next) + " entries at level " + std::to_string(level); return hipErrorUnknown; }
         if (next == 0) {
             if ((e = hipMemcpy(stack_need_out, s.collapse_counters + kCollapseNeedSlot, 4, hipMemcpyDeviceToHost))) return e;
             break;

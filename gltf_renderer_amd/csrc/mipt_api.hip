@@ -278,8 +278,13 @@ public:
             HIPOK(accel_refit(ctx->scratch, ctx->d_instances, ctx->d_touched, ctx->n_tris, ctx->wide_nodes, ctx->d_nodes, ctx->d_tris, ctx->d_shade, ctx->stream));
             ctx->accel_refits++;
         } else {
-            HIPOK(accel_build(ctx->scratch, ctx->d_buffers, ctx->d_instances, (int)ctx->instances.size(), ctx->n_tris, ctx->d_nodes, ctx->d_tris, ctx->d_shade,
-                              &ctx->root, &ctx->wide_nodes, &ctx->stack_need, ctx->stream));
+            ctx->scratch.why.clear();
+            const hipError_t be = accel_build(ctx->scratch, ctx->d_buffers, ctx->d_instances, (int)ctx->instances.size(), ctx->n_tris, ctx->d_nodes, ctx->d_tris,
+                                              ctx->d_shade, &ctx->root, &ctx->wide_nodes, &ctx->stack_need, ctx->stream);
+            if (be != hipSuccess) {
+                ctx->accel_built = false; ctx->accel_state = ACCEL_REBUILD;
+                return ctx->fail(PT_ERR_DEVICE, std::string("acceleration-structure build: ") + (ctx->scratch.why.empty() ? hipGetErrorString(be) : ctx->scratch.why.c_str()));
+            }
             ctx->accel_builds++;
         }
         HIPOK(hipEventRecord(ctx->ev_accel[1], ctx->stream));

@@ -34,6 +34,7 @@ struct AccelScratch {
     int32_t *ploc_left = nullptr, *ploc_right = nullptr;
     void* ploc_scan_temp = nullptr; size_t ploc_scan_bytes = 0;
     size_t capacity = 0;
+    std::string why;                         // what a failed build ran into (the hipError_t alone says "unknown error")
 };
 void accel_scratch_free(AccelScratch& s);
 // Builds the 4-wide BVH (<= n_tris nodes), the sorted intersection packets and their shading packets (n_tris each).

@@ -78,3 +78,43 @@ def test_animated_skinned_gltf_drives_the_dynamic_path(R, tmp_path):
     rest, _ = render_direct(R, s, 16)
     assert rel_l2(b, a) <= 1e-2, rel_l2(b, a)
     assert rel_l2(rest, a) > 5 * rel_l2(b, a)          # the pose matters: the bind pose is measurably a different image
+
+
+def test_unload_then_load_another_file_in_the_same_context(R, tmp_path):
+    """LoadGltf's flow (Main.cpp:43-54): Gltf::Unload, then the next file, in ONE context: the second scene must render exactly as in a
+    fresh context, the first scene's handles are gone and reused, and unloading twice is harmless."""
+    from gltf_renderer_amd.gltf import GltfScene
+    from gltf_renderer_amd import abi
+    s1, s2 = scenes.test_scene(96, 32), scenes.skinned_figure(96, 54)
+    p1 = scene_to_builder(s1).write_glb(str(tmp_path / "a.glb"))
+    p2 = skinned_figure_to_builder(s2).write_glb(str(tmp_path / "b.glb"))
+
+    def frame_of(r, sc, s, frames=4):
+        sc.calculate_global_transforms(0)
+        lights = sc.frame(r, 0)
+        assert lights == len(s.lights)
+        r.set_bounce_limit(s.bounce_limit)
+        out = r.create_output(s.width, s.height)
+        st = abi.PtSettings.from_buffer_copy(bytes(s.settings)); st.reset = 1
+        for f in range(frames):
+            r.trace(st, s.execute_params(f), out); st.reset = 0          # no environment map: the constant colour of the settings
+        return r.readback(out)
+
+    r = R()
+    a = GltfScene(p1); a.upload(r)
+    img_a = frame_of(r, a, s1)
+    tris_a = r.stats().bvh_triangles
+    a.unload(r); a.unload(r)
+    b = GltfScene(p2); b.upload(r)
+    img_b = frame_of(r, b, s2)
+    assert r.stats().bvh_triangles != tris_a
+    fresh = R()
+    b2 = GltfScene(p2); b2.upload(fresh)
+    assert np.array_equal(img_b, frame_of(fresh, b2, s2))
+    # and back again: the first file once more, into the handles the second one leaves behind
+    b.unload(r)
+    a2 = GltfScene(p1); a2.upload(r)
+    assert np.array_equal(img_a, frame_of(r, a2, s1))
+    for sc in (a, b, b2, a2):
+        sc.close()
+    r.close(); fresh.close()
