@@ -485,14 +485,15 @@ __global__ __launch_bounds__(1024) void k_collapse_small(const BvhNode* __restri
 // kernels assume (a left child is named by the LAST leaf of its range, a right child by the FIRST of its own -- unique per inner
 // node, root = 0), and the triangle packets are gathered into that order.
 #ifndef PT_PLOC_RADIUS
-#define PT_PLOC_RADIUS 8        // neighbours looked at on either side while the array is long (measured 8 / 16 / 32 / 64 / 128 on the Sponza-class
-                                // scene: 4820 / 4749 / 4744 / 4761 / 4619 Mrays/s at 8 spp)
+#define PT_PLOC_RADIUS 16       // neighbours looked at on either side (measured 4 / 8 / 16 / 32 with the integer ranking below, Mrays/s at 8 spp on the
+                                // Sponza-class scene / the material grid: 4804 / 2916, 4761 / 2999, 4878 / 3002, 4705 / 2968)
 #endif
-// (Order among partners of equal joint area, Mrays/s at 8 spp on the Sponza-class scene / the material grid: index distance then parity
+// (Order among partners of equal joint area, same two scenes, measured with an earlier float-comparison ranking: index distance then parity
 //  4750 / 3030; parity first 4739 / 3027; farthest first 4856 / 2923 and lower index only 4840 / 3021, both unsafe -- a strip of equal
-//  quads merges one pair per round; the more compact union first, then index distance and parity: 4813 / 3029 -- what k_ploc_nearest does.)
+//  quads merges one pair per round; the more compact union first, then index distance and parity: what k_ploc_nearest does.)
 #ifndef PT_PLOC_RADIUS_TOP
-#define PT_PLOC_RADIUS_TOP 8    // ... and once fewer than kPlocTopClusters clusters are left (the upper levels of the tree)
+#define PT_PLOC_RADIUS_TOP 16   // ... and once fewer than kPlocTopClusters clusters are left (the upper levels; a wider search there -- 32 / 128 / 512 -- was
+                                // measured and does not pay: greedy agglomeration does not profit from seeing further)
 #endif
 constexpr int kPlocRadius = PT_PLOC_RADIUS, kPlocRadiusTop = PT_PLOC_RADIUS_TOP, kPlocRadiusMax = PT_PLOC_RADIUS > PT_PLOC_RADIUS_TOP ? PT_PLOC_RADIUS : PT_PLOC_RADIUS_TOP;
 constexpr uint32_t kPlocTopClusters = 16384;
