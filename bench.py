@@ -148,19 +148,38 @@ def main():
     # ---- the one exchange per step: libmipt.so's own RCCL exchange; the torch.distributed double only for gloo rehearsals
     exchange_mode = args.exchange if world > 1 else "none"
     xch = None
+    exchange_impl = "libmipt.so (RCCL)"
     if world > 1 and args.backend == "nccl":
-        ids = [r.exchange_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)                # the host's transport for the 128-byte ncclUniqueId
-        r.exchange_create(rank, world, ids[0])
+        # the library's own exchange; should RCCL refuse to come up inside the library on some node (every rank must agree, hence
+        # the all-reduce of the outcome), the same exchange runs through torch.distributed on device tensors and the line says so
+        ok = 1
+        try:
+            ids = [r.exchange_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)            # the host's transport for the 128-byte ncclUniqueId
+            r.exchange_create(rank, world, ids[0])
+        except Exception as e:                                # noqa: BLE001
+            print("rank %d: pt_exchange_create failed (%s)" % (rank, e), file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            from gltf_renderer_amd.sharding import TileExchange
+            xch = TileExchange(s.width, s.height, world, "cuda")
+            exchange_impl = "torch.distributed fallback (pt_exchange_create failed on a rank)"
     elif world > 1:
         from gltf_renderer_amd.sharding import TileExchange
         xch = TileExchange(s.width, s.height, world, "cpu")
+        exchange_impl = "torch.distributed test double over gloo"
 
     def exchange(img):
         if world == 1:
             return
         if xch is None:                     # product path: RCCL inside the library, on the launch stream, assembled in place on rank 0
             r.exchange_frame(img, None, mode=abi.EXCHANGE_GATHER if exchange_mode == "gather" else abi.EXCHANGE_REDUCE, dst=0)
+        elif args.backend == "nccl":        # fallback: the same exchange through torch.distributed on device tensors
+            res = xch.gather_frame(img, rank) if exchange_mode == "gather" else xch.reduce_frame(img, rank)
+            if rank == 0 and res is not img:
+                img.copy_(res)
         else:                               # rehearsal: gloo moves host tensors
             host = img.cpu()
             res = xch.gather_frame(host, rank) if exchange_mode == "gather" else xch.reduce_frame(host, rank)
@@ -247,7 +266,7 @@ def main():
                        % (s.name, s.width, s.height, spp, settings.max_bounces, s.bounce_limit, settings.min_bounces,
                           settings.min_russian_roulette_continue_prob, settings.max_russian_roulette_continue_prob, s.triangles,
                           len(s.instances), len(s.textures), len(s.lights), settings.flags),
-                       "parallelism": ("tile-shard x%d + 1 RCCL exchange/step in libmipt.so (%s)" % (world, "own-tile gather to rank 0, point to point" if exchange_mode == "gather" else "ncclReduce of the zero-masked copy"))
+                       "parallelism": ("tile-shard x%d + 1 exchange/step by %s (%s)" % (world, exchange_impl, "own-tile gather to rank 0, point to point" if exchange_mode == "gather" else "reduce of the zero-masked copy"))
                                       if world > 1 else "single GPU",
                        "null_shadow_culling": bool(args.cull_null_shadow),
                        "samples_per_step": spp, "ms_per_1spp_frame": round(elapsed / args.steps / spp * 1000.0, 4),
