@@ -352,6 +352,10 @@ __device__ void wide_write(Bvh4Node* dst, const float (*lo)[3], const float (*hi
 //    holds kBvhWidth children or only leaves.  Compared with "keep every even level of the binary tree" this fills the slots (about
 //    3.0 -> 3.6 children per node on the Sponza-class scene), so the tree is shallower and a ray visits fewer nodes.
 //    counters[0]: wide nodes allocated so far; counters[1 + L]: size of level L's frontier.
+#ifndef PT_CHILD_ORDER
+#define PT_CHILD_ORDER 1      // children stored in decreasing surface area (measured 0 / 1 / 2 = as collapsed / by area / by triangle count, Mrays/s at 8 spp,
+                            // Sponza class: 4813 / 4906 / 4881; material grid 3002 / 3006 / 2982)
+#endif
 constexpr int kCollapseMaxLevels = 4096;
 constexpr int kCollapseNeedSlot = kCollapseMaxLevels + 8;       // counters[] slot: the deepest traversal stack any ray can need (entries)
 __device__ void collapse_one(const BvhNode* __restrict__ nodes2, uint32_t binary_node, uint32_t wide_index, uint32_t level,
@@ -434,6 +438,30 @@ __device__ void collapse_one(const BvhNode* __restrict__ nodes2, uint32_t binary
             slot++;
         }
     }
+#if PT_CHILD_ORDER
+    // Children in decreasing surface area (PT_CHILD_ORDER 1) / triangle count (2): occlusion rays enter the children in slot order
+    // (any hit ends them, so they skip the distance sort) and the biggest child is the likeliest to hold an occluder.  Closest-hit
+    // rays sort by distance anyway.  A 4-element sorting network on static indices (dynamic indexing would put the arrays in scratch).
+    {
+        float key[kBvhWidth];
+#pragma unroll
+        for (int k = 0; k < kBvhWidth; k++) {
+            const float dx = hi[k][0] - lo[k][0], dy = hi[k][1] - lo[k][1], dz = hi[k][2] - lo[k][2];
+            key[k] = k < cnt ? (PT_CHILD_ORDER == 2 ? (float)wr.count[k] : dx * dy + dy * dz + dz * dx) : -1.0f;
+        }
+#define PT_CSWAP_CHILD(A, B)                                                                                              \
+        if (key[A] < key[B]) {                                                                                             \
+            float tk = key[A]; key[A] = key[B]; key[B] = tk;                                                               \
+            int32_t tr = ref[A]; ref[A] = ref[B]; ref[B] = tr;                                                             \
+            uint32_t tf = wr.first[A]; wr.first[A] = wr.first[B]; wr.first[B] = tf;                                       \
+            uint32_t tc = wr.count[A]; wr.count[A] = wr.count[B]; wr.count[B] = tc;                                       \
+            for (int a = 0; a < 3; a++) { float t0 = lo[A][a]; lo[A][a] = lo[B][a]; lo[B][a] = t0; float t1 = hi[A][a]; hi[A][a] = hi[B][a]; hi[B][a] = t1; } \
+        }
+        static_assert(kBvhWidth == 4 || !PT_CHILD_ORDER, "child ordering is written for 4-wide nodes");
+        PT_CSWAP_CHILD(0, 1) PT_CSWAP_CHILD(2, 3) PT_CSWAP_CHILD(0, 2) PT_CSWAP_CHILD(1, 3) PT_CSWAP_CHILD(1, 2)
+#undef PT_CSWAP_CHILD
+    }
+#endif
     wide_write(out + wide_index, lo, hi, ref, cnt);
     ranges_out[wide_index] = wr;
 }
