@@ -446,7 +446,7 @@ def main():
         v_all, f_all = cpu_trace(cores, 10.0, max(sw // 8, 16), max(sh // 8, 16))       # 240x135 sample of the 1080p frame: same camera, same scene
         v_one, f_one = cpu_trace(1, 5.0, max(sw // 16, 16), max(sh // 16, 16))
         warm = {}
-        for name, b in (("radix_tree", abi.BUILDER_LBVH), ("ploc", abi.BUILDER_PLOC)):      # warm full builds of the bench scene, both builders
+        for name, b in (("radix_tree", abi.BUILDER_LBVH), ("ploc", abi.BUILDER_PLOC), ("ploc_reinsert", abi.BUILDER_PLOC_REINSERT)):      # warm full builds of the bench scene, every builder
             r.set_accel_builder(b)
             ms_b = []
             for _ in range(4):
@@ -454,7 +454,7 @@ def main():
             warm[name] = round(median(ms_b[1:]), 3)
         legs = {"B1_tracer_1_thread_Mrays": round(v_one, 4), "B1_tracer_all_cores_Mrays": round(v_all, 4),
                 "B2_cpu_lbvh_build_1_thread_ms": round(acc_ms, 2), "B2_hip_build_warm_ms": warm, "B2_hip_first_build_ms": round(accel_ms, 3), "B2_triangles": int(s.triangles),
-                "B2_note": "CPU: oracle LBVH (Morton, std::sort, Karras, bottom-up fit), single-threaded; HIP: full on-device builds (PLOC is the default builder; "
+                "B2_note": "CPU: oracle LBVH (Morton, std::sort, Karras, bottom-up fit), single-threaded; HIP: full on-device builds (PLOC + reinsertion is the default builder; "
                            "the first build also allocates); the reference's own BVH is built by the D3D12 driver"}
         # B2 refit + B4 skinning + B3 host work on the config-5 class scene (the dynamic path), GPU and CPU side by side
         try:

@@ -242,7 +242,7 @@ class PtStats(C.Structure):
 
 STAGE_NAMES = ("generate", "trace", "shade", "shadow", "resolve")
 EXCHANGE_GATHER, EXCHANGE_REDUCE = 0, 1
-BUILDER_LBVH, BUILDER_PLOC = 0, 1
+BUILDER_LBVH, BUILDER_PLOC, BUILDER_PLOC_REINSERT = 0, 1, 2
 EXCHANGE_ID_BYTES = 128
 
 

@@ -527,10 +527,11 @@ constexpr int kPlocRadius = PT_PLOC_RADIUS, kPlocRadiusTop = PT_PLOC_RADIUS_TOP,
 constexpr uint32_t kPlocTopClusters = 16384;
 struct PlocCluster { float lo[3]; int32_t ref; float hi[3]; uint32_t count; };     // 32 B; ref < 0: leaf ~(Morton index), >= 0: temporary node id
 static_assert(sizeof(PlocCluster) == 32, "PlocCluster");
-// counters: [0] temporary nodes made, [4] / [5] cluster count of even / odd rounds, [8 + L] layout frontier size of level L
-constexpr int kPlocLevelBase = 8;
+// counters: [0] temporary nodes made, [4] / [5] cluster count of even / odd rounds, [6] reinsertion moves, [7] layout error flag, [8 + L] layout frontier size of level L
+constexpr int kPlocLevelBase = 8, kPlocLayoutError = 7;
 
-__global__ __launch_bounds__(256) void k_ploc_init(const TriPacket* __restrict__ tris, uint32_t n, PlocCluster* __restrict__ c, uint32_t* __restrict__ counters) {
+__global__ __launch_bounds__(256) void k_ploc_init(const TriPacket* __restrict__ tris, uint32_t n, PlocCluster* __restrict__ c, uint32_t* __restrict__ counters,
+                                                   SegBox* __restrict__ t_box) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) { counters[0] = 0; counters[4] = n; counters[5] = n; }
     if (i >= n) return;
@@ -541,6 +542,9 @@ __global__ __launch_bounds__(256) void k_ploc_init(const TriPacket* __restrict__
     o.lo[0] = lo.x; o.lo[1] = lo.y; o.lo[2] = lo.z; o.ref = ~(int32_t)i;
     o.hi[0] = hi.x; o.hi[1] = hi.y; o.hi[2] = hi.z; o.count = 1;
     c[i] = o;
+    SegBox b;                                               // the reinsertion pass (4c) keeps every node's box: slots [0, n) are the leaves
+    b.lo[0] = lo.x; b.lo[1] = lo.y; b.lo[2] = lo.z; b._a = 0; b.hi[0] = hi.x; b.hi[1] = hi.y; b.hi[2] = hi.z; b._b = 0;
+    t_box[i] = b;
 }
 
 // the partner with the smallest joint surface area among the 2 * radius neighbours.  A pair is ranked by an INTEGER key that is the
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(256) void k_ploc_nearest(const PlocCluster* __restr
 // mutual pairs merge into the lower slot (a new temporary node); the upper slot is dropped by the compaction
 __global__ __launch_bounds__(256) void k_ploc_merge(PlocCluster* __restrict__ c, const uint32_t* __restrict__ n_ptr, const uint32_t* __restrict__ nn,
                                                     uint32_t* __restrict__ valid, int32_t* __restrict__ t_left, int32_t* __restrict__ t_right,
-                                                    uint32_t* __restrict__ t_count, uint32_t* __restrict__ counters) {
+                                                    uint32_t* __restrict__ t_count, uint32_t* __restrict__ counters, SegBox* __restrict__ t_box, uint32_t n_leaves) {
     const uint32_t n = *n_ptr;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -610,6 +614,9 @@ __global__ __launch_bounds__(256) void k_ploc_merge(PlocCluster* __restrict__ c,
     o.ref = (int32_t)idx; o.count = a.count + b.count;
     c[i] = o;
     valid[i] = 1u;
+    SegBox sb;                                              // slots [n_leaves, 2 n_leaves - 1): the temporary inner nodes
+    sb.lo[0] = o.lo[0]; sb.lo[1] = o.lo[1]; sb.lo[2] = o.lo[2]; sb._a = 0; sb.hi[0] = o.hi[0]; sb.hi[1] = o.hi[1]; sb.hi[2] = o.hi[2]; sb._b = 0;
+    t_box[n_leaves + idx] = sb;
 }
 
 __global__ __launch_bounds__(256) void k_ploc_compact(const PlocCluster* __restrict__ in, const uint32_t* __restrict__ n_ptr, const uint32_t* __restrict__ valid,
@@ -625,26 +632,214 @@ __global__ __launch_bounds__(256) void k_ploc_compact(const PlocCluster* __restr
     if (i == n - 1) *n_out = pos[i] + valid[i];
 }
 
+// ---- 4c. Parallel reinsertion (Meister & Bittner 2018, "Parallel Reinsertion for Bounding Volume Hierarchy Optimization") over the
+// clustering's binary tree, before it is laid out.  Greedy agglomeration decides every pair with what it sees in a window of the
+// Morton order; a subtree that ended up under the wrong parent stays there.  A pass lets EVERY node look for the place in the tree
+// where it would cost the least surface area: taking node `in` out removes its parent and shrinks the ancestors; putting it next
+// to a node `out` adds a parent for the two and grows out's ancestors.  The search is a branch-and-bound walk without a stack: up
+// the path to the root one ancestor (`pivot`) at a time, and down into the subtree hanging off each pivot for as long as the gain
+// so far, less the area of `in` itself, can still beat the best found.  Moves are then applied in parallel where they do not
+// touch: a move owns the tree path in -> top <- out (top = the lowest common ancestor, whose box the move leaves alone, or the
+// grandparent of `in` if that is higher: its child link changes); 64-bit atomicMax of
+// (gain bits, node) on every node of the path, highest gain wins, and a move is carried out only if it still holds its whole path.
+// Disjoint paths also rule out a cycle (two subtrees moved into each other), and they make the winners independent: every box and
+// triangle count a move changes lies on its own path, so the winner refits them itself and no tree-wide refit is needed.
+// Node slots: [0, n) leaves in Morton order, n + t the temporary inner node t.  Measured (tools/bvh_reinsert_probe.cpp, the same
+// algorithm on the CPU; inner-node area in root areas): Sponza class 61.4 -> 55.0 after 10 passes (binned SAH: 53.2), helmet
+// class 41.7 -> 38.8, material grid 16.7 -> 15.9.
+constexpr int kReinsMaxSteps = 8192;                         // bound on one node's search (a guard; the pruning ends a search long before)
+PT_DEV uint32_t ploc_slot(int32_t ref, uint32_t n) { return ref < 0 ? (uint32_t)~ref : n + (uint32_t)ref; }
+PT_DEV float box_area(const float4 lo, const float4 hi) {
+    const float dx = hi.x - lo.x, dy = hi.y - lo.y, dz = hi.z - lo.z;
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dy), __fmul_rn(dy, dz)), __fmul_rn(dz, dx));
+}
+PT_DEV float4 f4min(const float4 a, const float4 b) { return make_float4(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z), 0.f); }
+PT_DEV float4 f4max(const float4 a, const float4 b) { return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), 0.f); }
+
+// parent links (temporary inner index, -1 for the root) of every slot
+__global__ __launch_bounds__(256) void k_reins_parents(const int32_t* __restrict__ t_left, const int32_t* __restrict__ t_right, uint32_t n, const PlocCluster* __restrict__ root,
+                                                       int32_t* __restrict__ parent) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) parent[ploc_slot(root->ref, n)] = -1;
+    if (i >= n - 1) return;
+    parent[ploc_slot(t_left[i], n)] = (int32_t)i;
+    parent[ploc_slot(t_right[i], n)] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(256) void k_reins_find(const float4* __restrict__ box, const int32_t* __restrict__ parent, const int32_t* __restrict__ t_left,
+                                                    const int32_t* __restrict__ t_right, uint32_t n, float min_gain, float* __restrict__ gain,
+                                                    uint32_t* __restrict__ best_out, int32_t* __restrict__ best_top) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= 2 * n - 1) return;
+    float best = 0.0f;
+    uint32_t b_out = 0;
+    int32_t b_top = -1;
+    const int32_t p = parent[u];
+    if (p >= 0 && parent[n + p] >= 0) {                          // neither the root nor a child of the root moves
+        const float4 ilo = box[2 * u], ihi = box[2 * u + 1];
+        const float area_in = box_area(ilo, ihi);
+        float d_path = box_area(box[2 * (n + p)], box[2 * (n + p) + 1]);      // the parent goes away
+        float d = d_path;
+        // a move has to gain a fraction of the parent's area: the running sums carry rounding error of that scale, and a move made
+        // for a gain of rounding error is undone by the next pass (and holds its path against real moves meanwhile)
+        best = min_gain * d_path;
+        if (!(best >= 0.0f)) best = 0.0f;
+        int32_t pivot = p;
+        float4 plo = ilo, phi = ihi;                             // box of `pivot` without `in` (set when the search leaves pivot's subtree)
+        uint32_t out;
+        { const uint32_t l = ploc_slot(t_left[p], n); out = l == u ? ploc_slot(t_right[p], n) : l; }
+        bool down = true;
+        for (int step = 0; step < kReinsMaxSteps; step++) {
+            if (down) {
+                const float4 olo = box[2 * out], ohi = box[2 * out + 1];
+                const float merged = box_area(f4min(olo, ilo), f4max(ohi, ihi));
+                const float here = d - merged;
+                // (a move inside the parent's own subtree still re-links the grandparent: the owned path always reaches it)
+                if (here > best) { best = here; b_out = out; b_top = pivot == p ? parent[n + p] : pivot; }
+                const float grow = merged - box_area(olo, ohi);
+                // (written so that a NaN -- garbage vertices -- ends the descent)
+                if (out >= n && d - grow - area_in > best) { d -= grow; out = ploc_slot(t_left[out - n], n); }
+                else down = false;
+            } else {
+                const int32_t po = parent[out];
+                if (po == pivot) {
+                    // the subtree hanging off `pivot` is done: one ancestor up
+                    const float4 olo = box[2 * out], ohi = box[2 * out + 1];
+                    if (pivot == p) { plo = olo; phi = ohi; } else { plo = f4min(plo, olo); phi = f4max(phi, ohi); }
+                    const int32_t up = parent[n + pivot];
+                    if (up < 0) break;
+                    if (pivot != p) {
+                        const float a_pivot = box_area(box[2 * (n + pivot)], box[2 * (n + pivot) + 1]);
+                        d_path += a_pivot - box_area(plo, phi);                 // this ancestor shrinks
+                        const float here = d_path - a_pivot;                     // `in` as the sibling of the shrunk ancestor itself
+                        if (here > best) { best = here; b_out = n + (uint32_t)pivot; b_top = up; }
+                    }
+                    const uint32_t l = ploc_slot(t_left[up], n);
+                    out = l == n + (uint32_t)pivot ? ploc_slot(t_right[up], n) : l;
+                    pivot = up; d = d_path; down = true;
+                } else if (ploc_slot(t_left[po], n) == out) { out = ploc_slot(t_right[po], n); down = true; }
+                else {
+                    const float4 olo = box[2 * (n + po)], ohi = box[2 * (n + po) + 1];
+                    d += box_area(f4min(olo, ilo), f4max(ohi, ihi)) - box_area(olo, ohi);      // undo the growth charged on the way down
+                    out = n + (uint32_t)po;
+                }
+            }
+        }
+    }
+    gain[u] = b_top >= 0 ? best : 0.0f;
+    best_out[u] = b_out;
+    best_top[u] = b_top;
+}
+
+// One locking round.  LOCK = true: every candidate still in the race drops out if its path touches a path already won, else stamps
+// max(key) on in -> top <- out.  LOCK = false: a candidate that still holds every node of its path has won: it marks the path as
+// owned.  One round alone loses most moves to CHAINS -- A beats B on one node, B beats C on another, C is out although B never
+// moves -- (CPU model of this scheme, Sponza class, 8 passes: inner area 61.4 -> 57.3 with one round, 55.4 with two, 55.3 with
+// three or with sequential greedy selection), so a pass runs kReinsLockRounds of them.
+constexpr int kReinsLockRounds = 3;
+enum : uint8_t { REINS_CANDIDATE = 0, REINS_WON = 1, REINS_OUT = 2 };
+template <bool LOCK>
+__global__ __launch_bounds__(256) void k_reins_lock(const float* __restrict__ gain, const uint32_t* __restrict__ best_out, const int32_t* __restrict__ best_top,
+                                                    const int32_t* __restrict__ parent, uint32_t n, unsigned long long* __restrict__ lock, uint8_t* __restrict__ owned,
+                                                    uint8_t* __restrict__ state) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= 2 * n - 1) return;
+    const float g = gain[u];
+    if (!(g > 0.0f) || state[u] != REINS_CANDIDATE) return;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(g) << 32) | (unsigned long long)u;
+    const uint32_t top = n + (uint32_t)best_top[u];
+    // walk: 0 (LOCK only) is any node owned?  1 stamp / compare;  2 (verify only) mark as owned
+    for (int walk = LOCK ? 0 : 1; walk < (LOCK ? 2 : 3); walk++) {
+        bool ok = true;
+        for (int side = 0; side < 2 && ok; side++) {
+            uint32_t v = side == 0 ? u : best_out[u];
+            for (int k = 0; k < 256 && v != top; k++) {
+                if (walk == 0) ok = ok && !owned[v];
+                else if (walk == 2) owned[v] = 1;
+                else if (LOCK) atomicMax(lock + v, key);
+                else ok = ok && lock[v] == key;
+                const int32_t pv = parent[v];
+                if (pv < 0) { ok = false; break; }               // cannot happen: top is an ancestor of both ends
+                v = n + (uint32_t)pv;
+            }
+            if (v != top) ok = false;
+        }
+        if (walk == 0) ok = ok && !owned[top];
+        else if (walk == 2) owned[top] = 1;
+        else if (LOCK) atomicMax(lock + top, key);
+        else ok = ok && lock[top] == key;
+        if (walk == 0 && !ok) { state[u] = REINS_OUT; return; }
+        if (walk == 1 && !LOCK) { if (!ok) return; state[u] = REINS_WON; }
+    }
+}
+
+PT_DEV void reins_refit_node(float4* __restrict__ box, const int32_t* __restrict__ t_left, const int32_t* __restrict__ t_right, uint32_t* __restrict__ t_count,
+                             uint32_t n, int32_t v) {
+    const int32_t l = t_left[v], r = t_right[v];
+    const uint32_t ls = ploc_slot(l, n), rs = ploc_slot(r, n);
+    box[2 * (n + v)] = f4min(box[2 * ls], box[2 * rs]);
+    box[2 * (n + v) + 1] = f4max(box[2 * ls + 1], box[2 * rs + 1]);
+    t_count[v] = (l < 0 ? 1u : t_count[l]) + (r < 0 ? 1u : t_count[r]);
+}
+
+// carry out the surviving moves: their paths are disjoint, so each thread edits and refits only nodes it owns
+__global__ __launch_bounds__(256) void k_reins_apply(const uint8_t* __restrict__ state, const uint32_t* __restrict__ best_out, const int32_t* __restrict__ best_top,
+                                                     int32_t* __restrict__ parent, int32_t* __restrict__ t_left, int32_t* __restrict__ t_right,
+                                                     uint32_t* __restrict__ t_count, float4* __restrict__ box, uint32_t n, uint32_t* __restrict__ applied) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= 2 * n - 1 || state[u] != REINS_WON) return;
+    const int32_t u_ref = u < n ? ~(int32_t)u : (int32_t)(u - n);
+    const int32_t p = parent[u], g = parent[n + p], top = best_top[u];
+    const int32_t s_ref = t_left[p] == u_ref ? t_right[p] : t_left[p];
+    // out: the sibling takes the parent's place
+    if (t_left[g] == p) t_left[g] = s_ref; else t_right[g] = s_ref;
+    parent[ploc_slot(s_ref, n)] = g;
+    // in: the freed parent node goes between `out` and its parent
+    const uint32_t o = best_out[u];
+    const int32_t o_ref = o < n ? ~(int32_t)o : (int32_t)(o - n);
+    const int32_t po = parent[o];
+    if (t_left[po] == o_ref) t_left[po] = p; else t_right[po] = p;
+    parent[n + p] = po;
+    t_left[p] = o_ref; t_right[p] = u_ref;
+    parent[o] = p;
+    for (int side = 0; side < 2; side++) {
+        int32_t v = side == 0 ? g : p;
+        for (int k = 0; k < 256 && v >= 0 && v != top; k++) { reins_refit_node(box, t_left, t_right, t_count, n, v); v = parent[n + v]; }
+    }
+    atomicAdd(applied, 1u);
+}
+
 // layout, one level per launch: frontier entry = (temporary node, first leaf position, final index)
 __global__ __launch_bounds__(256) void k_ploc_layout_init(const PlocCluster* __restrict__ c, uint32_t* __restrict__ f_node, uint32_t* __restrict__ f_first,
                                                           uint32_t* __restrict__ f_index, uint32_t* __restrict__ counters) {
     for (int k = threadIdx.x; k < kCollapseMaxLevels; k += 256) counters[kPlocLevelBase + k] = k == 0 ? 1u : 0u;
-    if (threadIdx.x == 0) { f_node[0] = (uint32_t)c[0].ref; f_first[0] = 0u; f_index[0] = 0u; }
+    if (threadIdx.x == 0) { f_node[0] = (uint32_t)c[0].ref; f_first[0] = 0u; f_index[0] = 0u; counters[kPlocLayoutError] = 0u; }
 }
 __global__ __launch_bounds__(256) void k_ploc_layout_level(const int32_t* __restrict__ t_left, const int32_t* __restrict__ t_right, const uint32_t* __restrict__ t_count,
                                                            const uint32_t* __restrict__ f_node, const uint32_t* __restrict__ f_first, const uint32_t* __restrict__ f_index,
                                                            uint32_t level, uint32_t* __restrict__ o_node, uint32_t* __restrict__ o_first, uint32_t* __restrict__ o_index,
-                                                           uint32_t* __restrict__ counters, BvhNode* __restrict__ nodes2, uint32_t* __restrict__ perm) {
+                                                           uint32_t* __restrict__ counters, BvhNode* __restrict__ nodes2, uint32_t* __restrict__ perm, uint32_t n_nodes) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool active = i < counters[kPlocLevelBase + level];
+    // (a frontier can only exceed the node count if the links do not form a tree; the host sees the count and fails the build --
+    //  nothing is written past the arrays meanwhile)
+    bool active = i < counters[kPlocLevelBase + level] && i < n_nodes;
     int32_t l = -1, r = -1;
     uint32_t first = 0, lc = 0;
     if (active) {
         const uint32_t t = f_node[i], me = f_index[i];
         first = f_first[i];
-        l = t_left[t]; r = t_right[t];
-        const uint32_t cnt = t_count[t];
-        lc = l < 0 ? 1u : t_count[l];
+        const uint32_t cnt = t < n_nodes ? t_count[t] : 0u;
+        if (t < n_nodes) { l = t_left[t]; r = t_right[t]; }
+        lc = l < 0 ? 1u : ((uint32_t)l < n_nodes ? t_count[l] : 0u);
+        // links that do not describe a tree over exactly these leaves: flag it, write nothing
+        if (t >= n_nodes || me >= n_nodes || cnt < 2u || lc == 0u || lc >= cnt || first + cnt > n_nodes + 1u || (l >= 0 && (uint32_t)l >= n_nodes) ||
+            (r >= 0 && (uint32_t)r >= n_nodes) || (l < 0 && (uint32_t)~l > n_nodes) || (r < 0 && (uint32_t)~r > n_nodes)) {
+            counters[kPlocLayoutError] = 1u; active = false; l = r = -1;
+        }
+    }
+    if (active) {
+        const uint32_t me = f_index[i];
+        const uint32_t cnt = t_count[f_node[i]];
         BvhNode& n = nodes2[me];
         n.child0 = l < 0 ? ~(int32_t)first : (int32_t)(first + lc - 1u);
         n.child1 = r < 0 ? ~(int32_t)(first + lc) : (int32_t)(first + lc);
@@ -664,6 +859,7 @@ __global__ __launch_bounds__(256) void k_ploc_layout_level(const int32_t* __rest
         base = __shfl(base, leader, 64);
         if (push) {
             const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (at >= n_nodes) continue;
             o_node[at] = (uint32_t)(side == 0 ? l : r);
             o_first[at] = side == 0 ? first : first + lc;
             o_index[at] = side == 0 ? first + lc - 1u : first + lc;
@@ -675,7 +871,7 @@ __global__ __launch_bounds__(256) void k_ploc_layout_level(const int32_t* __rest
 __global__ __launch_bounds__(256) void k_ploc_gather(const TriPacket* __restrict__ in, const uint32_t* __restrict__ perm, uint32_t n, TriPacket* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float4* s4 = (const float4*)(in + perm[i]);
+    const float4* s4 = (const float4*)(in + min(perm[i], n - 1u));
     float4* d4 = (float4*)(out + i);
     d4[0] = s4[0]; d4[1] = s4[1]; d4[2] = s4[2];
 }
@@ -686,16 +882,18 @@ static void free_all(AccelScratch& s) {
     hipFree(s.nodes2); hipFree(s.kept); hipFree(s.widx); hipFree(s.collapse_counters); hipFree(s.wide_ranges);
     hipFree(s.ploc_c[0]); hipFree(s.ploc_c[1]); hipFree(s.ploc_nn); hipFree(s.ploc_valid); hipFree(s.ploc_pos); hipFree(s.ploc_left); hipFree(s.ploc_right);
     hipFree(s.ploc_count); hipFree(s.ploc_perm); hipFree(s.ploc_scan_temp); hipFree(s.ploc_counters);
+    hipFree(s.reins_box); hipFree(s.reins_parent); hipFree(s.reins_gain); hipFree(s.reins_out); hipFree(s.reins_top); hipFree(s.reins_lock); hipFree(s.reins_state);
 }
 
 static hipError_t ensure(AccelScratch& s, size_t n) {
     if (n <= s.capacity) return hipSuccess;
     free_all(s);
     uint32_t* bounds = s.bounds;
-    const int builder = s.builder;
+    const int builder = s.builder, passes = s.reinsert_passes;
+    const float min_gain = s.reinsert_min_gain;
     s = AccelScratch();
     s.bounds = bounds;
-    s.builder = builder;
+    s.builder = builder; s.reinsert_passes = passes; s.reinsert_min_gain = min_gain;
     size_t cap = n + n / 8 + 64;
     hipError_t e;
     if ((e = hipMalloc(&s.tris_unsorted, cap * sizeof(TriPacket)))) return e;
@@ -729,6 +927,14 @@ static hipError_t ensure(AccelScratch& s, size_t n) {
     if ((e = hipMalloc(&s.ploc_count, cap * 4))) return e;
     if ((e = hipMalloc(&s.ploc_perm, cap * 4))) return e;
     if ((e = hipMalloc(&s.ploc_counters, (kCollapseMaxLevels + 16) * 4))) return e;
+    // reinsertion (4c): per node slot (2 n - 1 of them) box, parent, best move, path lock
+    if ((e = hipMalloc(&s.reins_box, 2 * cap * 32))) return e;
+    if ((e = hipMalloc(&s.reins_parent, 2 * cap * 4))) return e;
+    if ((e = hipMalloc(&s.reins_gain, 2 * cap * 4))) return e;
+    if ((e = hipMalloc(&s.reins_out, 2 * cap * 4))) return e;
+    if ((e = hipMalloc(&s.reins_top, 2 * cap * 4))) return e;
+    if ((e = hipMalloc(&s.reins_lock, 2 * cap * 8))) return e;
+    if ((e = hipMalloc(&s.reins_state, 4 * cap))) return e;
     size_t sb = 0;
     if ((e = rocprim::exclusive_scan(nullptr, sb, s.ploc_valid, s.ploc_pos, 0u, cap, rocprim::plus<uint32_t>(), (hipStream_t)0))) return e;
     if ((e = hipMalloc(&s.ploc_scan_temp, sb))) return e;
@@ -740,9 +946,10 @@ static hipError_t ensure(AccelScratch& s, size_t n) {
 void accel_scratch_free(AccelScratch& s) {
     free_all(s);
     hipFree(s.bounds);
-    const int builder = s.builder;
+    const int builder = s.builder, passes = s.reinsert_passes;
+    const float min_gain = s.reinsert_min_gain;
     s = AccelScratch();
-    s.builder = builder;
+    s.builder = builder; s.reinsert_passes = passes; s.reinsert_min_gain = min_gain;
 }
 
 // The segment tree over the sorted triangles' boxes (all levels), from the packets as they stand.
@@ -763,7 +970,7 @@ static hipError_t ploc_build(AccelScratch& s, uint32_t n_tris, TriPacket* d_tris
     hipError_t e;
     PlocCluster* c[2] = {(PlocCluster*)s.ploc_c[0], (PlocCluster*)s.ploc_c[1]};
     uint32_t* cnt = s.ploc_counters;
-    hipLaunchKernelGGL(k_ploc_init, dim3((n_tris + 255) / 256), dim3(256), 0, stream, (const TriPacket*)d_tris, n_tris, c[0], cnt);
+    hipLaunchKernelGGL(k_ploc_init, dim3((n_tris + 255) / 256), dim3(256), 0, stream, (const TriPacket*)d_tris, n_tris, c[0], cnt, (SegBox*)s.reins_box);
     uint32_t bound = n_tris;
     int round = 0;
     for (;;) {
@@ -773,7 +980,7 @@ static hipError_t ploc_build(AccelScratch& s, uint32_t n_tris, TriPacket* d_tris
             const dim3 grid((bound + 255) / 256);
             hipLaunchKernelGGL(k_ploc_nearest, grid, dim3(256), 0, stream, (const PlocCluster*)c[a], (const uint32_t*)(cnt + 4 + a), s.ploc_nn);
             hipLaunchKernelGGL(k_ploc_merge, grid, dim3(256), 0, stream, c[a], (const uint32_t*)(cnt + 4 + a), (const uint32_t*)s.ploc_nn, s.ploc_valid, s.ploc_left,
-                               s.ploc_right, s.ploc_count, cnt);
+                               s.ploc_right, s.ploc_count, cnt, (SegBox*)s.reins_box, n_tris);
             size_t sb = s.ploc_scan_bytes;
             if ((e = rocprim::exclusive_scan(s.ploc_scan_temp, sb, s.ploc_valid, s.ploc_pos, 0u, (size_t)bound, rocprim::plus<uint32_t>(), stream))) return e;
             hipLaunchKernelGGL(k_ploc_compact, grid, dim3(256), 0, stream, (const PlocCluster*)c[a], (const uint32_t*)(cnt + 4 + a), (const uint32_t*)s.ploc_valid,
@@ -788,6 +995,34 @@ static hipError_t ploc_build(AccelScratch& s, uint32_t n_tris, TriPacket* d_tris
         if (n_cur == 1) break;
         bound = n_cur;
     }
+    // reinsertion passes over the finished topology (4c)
+    if (s.builder == 2 && n_tris >= 4) {
+        const uint32_t total = 2 * n_tris - 1;
+        const dim3 grid((total + 255) / 256);
+        hipLaunchKernelGGL(k_reins_parents, dim3((n_tris + 255) / 256), dim3(256), 0, stream, (const int32_t*)s.ploc_left, (const int32_t*)s.ploc_right, n_tris,
+                           (const PlocCluster*)c[round & 1], s.reins_parent);
+        if ((e = hipMemsetAsync(cnt + 6, 0, 4, stream))) return e;
+        for (int pass = 0; pass < s.reinsert_passes; pass++) {
+            hipLaunchKernelGGL(k_reins_find, grid, dim3(256), 0, stream, (const float4*)s.reins_box, (const int32_t*)s.reins_parent, (const int32_t*)s.ploc_left,
+                               (const int32_t*)s.ploc_right, n_tris, s.reinsert_min_gain, s.reins_gain, s.reins_out, s.reins_top);
+            if ((e = hipMemsetAsync(s.reins_state, 0, (size_t)total * 2, stream))) return e;             // state[total] and owned[total], contiguous
+            for (int lr = 0; lr < kReinsLockRounds; lr++) {
+                if ((e = hipMemsetAsync(s.reins_lock, 0, (size_t)total * 8, stream))) return e;
+                hipLaunchKernelGGL(k_reins_lock<true>, grid, dim3(256), 0, stream, (const float*)s.reins_gain, (const uint32_t*)s.reins_out, (const int32_t*)s.reins_top,
+                                   (const int32_t*)s.reins_parent, n_tris, s.reins_lock, s.reins_state + total, s.reins_state);
+                hipLaunchKernelGGL(k_reins_lock<false>, grid, dim3(256), 0, stream, (const float*)s.reins_gain, (const uint32_t*)s.reins_out, (const int32_t*)s.reins_top,
+                                   (const int32_t*)s.reins_parent, n_tris, s.reins_lock, s.reins_state + total, s.reins_state);
+            }
+            hipLaunchKernelGGL(k_reins_apply, grid, dim3(256), 0, stream, (const uint8_t*)s.reins_state, (const uint32_t*)s.reins_out, (const int32_t*)s.reins_top,
+                               s.reins_parent, s.ploc_left, s.ploc_right, s.ploc_count, (float4*)s.reins_box, n_tris, cnt + 6);
+            if (getenv("MIPT_DEBUG_PLOC")) {
+                uint32_t moved = 0;
+                if ((e = hipMemcpyAsync(&moved, cnt + 6, 4, hipMemcpyDeviceToHost, stream))) return e;
+                if ((e = hipStreamSynchronize(stream))) return e;
+                fprintf(stderr, "reinsertion pass %d: %u moves so far\n", pass + 1, moved);
+            }
+        }
+    }
     // layout: ranges, final indices, final triangle order
     uint32_t* fn[2] = {s.kept, s.vals_a};
     uint32_t* ff[2] = {s.widx, s.vals_b};
@@ -800,12 +1035,15 @@ static hipError_t ploc_build(AccelScratch& s, uint32_t n_tris, TriPacket* d_tris
         for (int j = 0; j < 8; j++, level++, cur ^= 1u) {
             hipLaunchKernelGGL(k_ploc_layout_level, dim3((fb + 255) / 256), dim3(256), 0, stream, (const int32_t*)s.ploc_left, (const int32_t*)s.ploc_right,
                                (const uint32_t*)s.ploc_count, (const uint32_t*)fn[cur], (const uint32_t*)ff[cur], (const uint32_t*)fi[cur], level, fn[cur ^ 1u], ff[cur ^ 1u],
-                               fi[cur ^ 1u], cnt, s.nodes2, s.ploc_perm);
+                               fi[cur ^ 1u], cnt, s.nodes2, s.ploc_perm, n_nodes);
             fb = fb > n_nodes / 2 ? n_nodes : fb * 2;
         }
         uint32_t next = 0;
+        uint32_t bad = 0;
         if ((e = hipMemcpyAsync(&next, cnt + kPlocLevelBase + level, 4, hipMemcpyDeviceToHost, stream))) return e;
+        if ((e = hipMemcpyAsync(&bad, cnt + kPlocLayoutError, 4, hipMemcpyDeviceToHost, stream))) return e;
         if ((e = hipStreamSynchronize(stream))) return e;
+        if (bad) { s.why = "PLOC: the clustered links do not form a tree over the triangles (layout level " + std::to_string(level) + ")"; return hipErrorUnknown; }
         if (next > n_nodes) { s.why = "PLOC: layout frontier of " + std::to_string(next) + " entries at level " + std::to_string(level); return hipErrorUnknown; }
         if (next == 0) break;
         fb = next;
@@ -836,7 +1074,7 @@ hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const Instan
     size_t tb = s.sort_temp_bytes;
     if ((e = rocprim::radix_sort_pairs(s.sort_temp, tb, s.keys_a, s.keys_b, s.vals_a, s.vals_b, (size_t)n_tris, 0, 63, stream))) return e;
     hipLaunchKernelGGL(k_reorder, dim3(g), dim3(256), 0, stream, s.tris_unsorted, s.vals_b, n_tris, d_tris);
-    bool radix = s.builder != 1;
+    bool radix = s.builder == 0;
     if (!radix) {
         e = ploc_build(s, n_tris, d_tris, stream);
         // the clustering must merge at least its globally best pair every round; if it ever does not (inconsistent arithmetic), the

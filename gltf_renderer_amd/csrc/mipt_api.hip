@@ -531,9 +531,18 @@ int pt_create(int device, void* hip_stream, const float* sheen_e_16x16, pt_ctx**
     ok = ok && hipEventCreateWithFlags(&ctx->bones_fence, hipEventDisableTiming) == hipSuccess;
     if (!ok) { pt_destroy(ctx); return PT_ERR_DEVICE; }
     ctx->samplers.push_back({PT_ADDRESS_WRAP, PT_ADDRESS_WRAP, PT_FILTER_LINEAR, PT_FILTER_LINEAR});   // sampler 0 (GpuResources.cpp:47-59)
-    if (const char* b = getenv("MIPT_ACCEL_BUILDER")) {      // initial builder of new contexts (pt_set_accel_builder overrides): "lbvh" | "ploc"
+    if (const char* b = getenv("MIPT_ACCEL_BUILDER")) {      // initial builder of new contexts (pt_set_accel_builder overrides): "lbvh" | "ploc" | "reinsert"
         if (!strcmp(b, "ploc")) ctx->scratch.builder = PT_BUILDER_PLOC;
         else if (!strcmp(b, "lbvh")) ctx->scratch.builder = PT_BUILDER_LBVH;
+        else if (!strcmp(b, "reinsert")) ctx->scratch.builder = PT_BUILDER_PLOC_REINSERT;
+    }
+    if (const char* b = getenv("MIPT_REINSERT_PASSES")) {    // tuning aid (tools/builder_probe.py): passes of PT_BUILDER_PLOC_REINSERT
+        const int v = atoi(b);
+        if (v >= 0 && v <= 64) ctx->scratch.reinsert_passes = v;
+    }
+    if (const char* b = getenv("MIPT_REINSERT_MIN_GAIN")) {
+        const float v = (float)atof(b);
+        if (v >= 0.0f && v < 1.0f) ctx->scratch.reinsert_min_gain = v;
     }
     *out = ctx;
     return PT_OK;
@@ -878,7 +887,7 @@ int pt_accel_request_rebuild(pt_ctx* ctx) {
 }
 
 int pt_set_accel_builder(pt_ctx* ctx, int builder) {
-    if (!ctx || (builder != PT_BUILDER_LBVH && builder != PT_BUILDER_PLOC)) return PT_ERR_INVALID_ARGUMENT;
+    if (!ctx || builder < PT_BUILDER_LBVH || builder > PT_BUILDER_PLOC_REINSERT) return PT_ERR_INVALID_ARGUMENT;
     if (ctx->scratch.builder != builder) { ctx->scratch.builder = builder; ctx->accel_state = ACCEL_REBUILD; }
     return PT_OK;
 }

@@ -28,7 +28,11 @@ struct AccelScratch {
     uint32_t* collapse_counters = nullptr;   // greedy collapse: [0] wide nodes allocated, [1 + L] frontier size of level L
     WideRanges* wide_ranges = nullptr;       // per wide node: the sorted-triangle range under each child (kept for accel_refit)
     // PLOC builder (accel.hip 4b)
-    int builder = 1;                         // PT_BUILDER_*: 0 radix tree (Karras LBVH); 1 PLOC clustering over the same Morton order (default)
+    int builder = 2;                         // PT_BUILDER_*: 0 radix tree (Karras LBVH); 1 PLOC clustering over the same Morton order; 2 PLOC + reinsertion passes (default)
+    float reinsert_min_gain = 1e-3f;         // ... a move must gain this fraction of its parent's surface area
+    int reinsert_passes = 8;                 // builder 2: passes of parallel reinsertion over the clustered tree (accel.hip 4c)
+    void* reins_box = nullptr; int32_t *reins_parent = nullptr, *reins_top = nullptr; float* reins_gain = nullptr; uint32_t* reins_out = nullptr;
+    unsigned long long* reins_lock = nullptr; uint8_t* reins_state = nullptr;
     void* ploc_c[2] = {nullptr, nullptr};    // cluster arrays (ping-pong)
     uint32_t *ploc_nn = nullptr, *ploc_valid = nullptr, *ploc_pos = nullptr, *ploc_count = nullptr, *ploc_perm = nullptr, *ploc_counters = nullptr;
     int32_t *ploc_left = nullptr, *ploc_right = nullptr;

@@ -236,7 +236,8 @@ class Renderer:
         self._check(self.L.pt_accel_request_rebuild(self.h))
 
     def set_accel_builder(self, builder):
-        """abi.BUILDER_LBVH (radix tree) or abi.BUILDER_PLOC (clustering by surface area: better tree, slower build)."""
+        """abi.BUILDER_LBVH (radix tree), abi.BUILDER_PLOC (clustering by surface area: better tree, slower build) or
+        abi.BUILDER_PLOC_REINSERT (the default: the PLOC tree improved by parallel reinsertion passes)."""
         self._check(self.L.pt_set_accel_builder(self.h, int(builder)))
 
     def enable_stage_timing(self, on):

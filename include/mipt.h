@@ -376,15 +376,18 @@ int pt_env_destroy(pt_ctx* ctx, int env);
  * pt_accel_request_rebuild forces the next call to build from scratch (e.g. after a pose has drifted far from the built one). */
 int pt_build_accel(pt_ctx* ctx);
 int pt_accel_request_rebuild(pt_ctx* ctx);
-/* Which builder a full build uses (both on-device, both over the Morton order of the triangles' centroids):
+/* Which builder a full build uses (all on-device, all over the Morton order of the triangles' centroids):
  *   PT_BUILDER_LBVH  the radix tree of the sorted codes (Karras 2012): the fastest build (0.6 ms at 257 k triangles);
- *   PT_BUILDER_PLOC  (default) parallel locally-ordered clustering (Meister & Bittner 2018) over the same order: neighbours
+ *   PT_BUILDER_PLOC  parallel locally-ordered clustering (Meister & Bittner 2018) over the same order: neighbours
  *                    merge by joint surface area, bottom-up -- a better tree (7-35 % fewer node visits per ray on the BASELINE
  *                    scenes) for four times the build time (2.3 ms): the counterpart of the reference's PREFER_FAST_TRACE
- *                    static BLAS (RayTracingAccelerationStructure.cpp:228-290).  Same hits either way.
- * Changing it makes the next pt_build_accel a full build.  The refit works on either.  The environment variable
- * MIPT_ACCEL_BUILDER = "lbvh" | "ploc" sets the builder new contexts start with. */
-enum { PT_BUILDER_LBVH = 0, PT_BUILDER_PLOC = 1 };
+ *                    static BLAS (RayTracingAccelerationStructure.cpp:228-290);
+ *   PT_BUILDER_PLOC_REINSERT  (default) the PLOC tree improved by passes of parallel reinsertion (Meister & Bittner 2018): every
+ *                    node looks for the place in the tree where it costs the least surface area and the moves that do not
+ *                    touch each other are carried out, eight times over.
+ * Same hits whichever builds.  Changing it makes the next pt_build_accel a full build.  The refit works on all.  The environment
+ * variable MIPT_ACCEL_BUILDER = "lbvh" | "ploc" | "reinsert" sets the builder new contexts start with. */
+enum { PT_BUILDER_LBVH = 0, PT_BUILDER_PLOC = 1, PT_BUILDER_PLOC_REINSERT = 2 };
 int pt_set_accel_builder(pt_ctx* ctx, int builder);
 
 /* GpuSkin::Run (Source/GpuSkin.cpp:57-118).  bones may be NULL (no skinning, quirk q19 kept). */

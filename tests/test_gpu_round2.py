@@ -124,13 +124,15 @@ def test_refit_matches_full_rebuild_static_scene_plus_skinned_figure(R):
 
 
 def test_builders_agree_and_ploc_visits_fewer_nodes(R):
-    """pt_set_accel_builder: the radix tree and the PLOC tree are different trees over the same triangles -- identical closest hits
-    (bit-identical debug images: the triangle test does not know the tree), identical ray counts, and on the config-4 class scene
-    (spheres over a floor: where spatial-median splits are at their worst) clearly fewer node visits per ray with PLOC."""
+    """pt_set_accel_builder: the radix tree, the PLOC tree and the PLOC tree after the reinsertion passes are different trees over
+    the same triangles -- identical closest hits (bit-identical debug images: the triangle test does not know the tree), identical
+    ray counts, and on the config-4 class scene (spheres over a floor: where spatial-median splits are at their worst) clearly
+    fewer node visits per ray with PLOC, fewer again after reinsertion."""
     s = scenes.material_grid(256, seg=24)
     imgs, per_ray, rays = {}, {}, {}
-    for name, b in (("lbvh", abi.BUILDER_LBVH), ("ploc", abi.BUILDER_PLOC)):
-        r = R(); r.set_accel_builder(b)
+    for name, b in (("lbvh", abi.BUILDER_LBVH), ("ploc", abi.BUILDER_PLOC), ("reins", abi.BUILDER_PLOC_REINSERT)):
+        r = R()
+        if b != abi.BUILDER_PLOC_REINSERT: r.set_accel_builder(b)              # (the default: a fresh context must already use it)
         h = s.upload(r)
         imgs[name] = [debug_image(r, s, h, d) for d in (abi.DEBUG_OUTPUT_HIT_KIND, abi.DEBUG_OUTPUT_TEXCOORD_0, abi.DEBUG_OUTPUT_VERTEX_NORMAL)]
         q = r.stats()
@@ -148,11 +150,12 @@ def test_builders_agree_and_ploc_visits_fewer_nodes(R):
         again = debug_image(r, s, h, abi.DEBUG_OUTPUT_TEXCOORD_0)
         assert r.stats().accel_builds == 2 and (np.abs(again - imgs[name][1]).max(axis=2) > 0).mean() < 1e-4
         r.close()
-    for a, b in zip(imgs["lbvh"][:3], imgs["ploc"][:3]):
-        assert (np.abs(a - b).max(axis=2) > 0).mean() < 1e-4              # exact-t ties on shared edges only
-    assert (np.abs(imgs["lbvh"][3] - imgs["ploc"][3]).max(axis=2) > 0).mean() < 2e-3 and abs(rays["lbvh"] - rays["ploc"]) <= 1e-4 * rays["lbvh"]
-    print("nodes per ray, config-4 class: radix tree %.2f, PLOC %.2f" % (per_ray["lbvh"], per_ray["ploc"]))
-    assert per_ray["ploc"] < 0.9 * per_ray["lbvh"]
+    for other in ("ploc", "reins"):
+        for a, b in zip(imgs["lbvh"][:3], imgs[other][:3]):
+            assert (np.abs(a - b).max(axis=2) > 0).mean() < 1e-4          # exact-t ties on shared edges only
+        assert (np.abs(imgs["lbvh"][3] - imgs[other][3]).max(axis=2) > 0).mean() < 2e-3 and abs(rays["lbvh"] - rays[other]) <= 1e-4 * rays["lbvh"]
+    print("nodes per ray, config-4 class: radix tree %.2f, PLOC %.2f, PLOC + reinsertion %.2f" % (per_ray["lbvh"], per_ray["ploc"], per_ray["reins"]))
+    assert per_ray["ploc"] < 0.9 * per_ray["lbvh"] and per_ray["reins"] < 0.98 * per_ray["ploc"]
 
 
 def test_coincident_and_garbage_triangles_build_or_fail_loudly(R):
@@ -171,11 +174,13 @@ def test_coincident_and_garbage_triangles_build_or_fail_loudly(R):
     s = scenes.single_triangle(64)
     s.instances.clear(); s.mesh_records.clear(); s.buffers.clear(); s.triangles = 0
     s.add_mesh(many, None, 0)
-    r = R(); r.set_accel_builder(abi.BUILDER_PLOC); h = s.upload(r)
-    img = debug_image(r, s, h, abi.DEBUG_OUTPUT_HIT_KIND)
-    q = r.stats()
-    assert q.bvh_triangles == n and q.bvh_stack_need <= 64
-    assert np.array_equal(img, ref)                             # the same silhouette, whichever copy is hit
+    for b in (abi.BUILDER_PLOC, abi.BUILDER_PLOC_REINSERT):
+        r = R(); r.set_accel_builder(b); h = s.upload(r)
+        img = debug_image(r, s, h, abi.DEBUG_OUTPUT_HIT_KIND)
+        q = r.stats()
+        assert q.bvh_triangles == n and q.bvh_stack_need <= 64
+        assert np.array_equal(img, ref)                         # the same silhouette, whichever copy is hit
+        if b == abi.BUILDER_PLOC: r.close()
     r.set_accel_builder(abi.BUILDER_LBVH)
     try:
         img2 = debug_image(r, s, h, abi.DEBUG_OUTPUT_HIT_KIND)
@@ -190,7 +195,7 @@ def test_coincident_and_garbage_triangles_build_or_fail_loudly(R):
     s2 = scenes.single_triangle(32)
     s2.instances.clear(); s2.mesh_records.clear(); s2.buffers.clear(); s2.triangles = 0
     s2.add_mesh(meshgen.Mesh(bad, np.arange(900), normals=np.tile(np.array([[0, -1, 0]], f32), (900, 1))), None, 0)
-    for b in (abi.BUILDER_PLOC, abi.BUILDER_LBVH):
+    for b in (abi.BUILDER_PLOC_REINSERT, abi.BUILDER_PLOC, abi.BUILDER_LBVH):
         r = R(); r.set_accel_builder(b); h = s2.upload(r)
         try:
             out = debug_image(r, s2, h, abi.DEBUG_OUTPUT_HIT_KIND)

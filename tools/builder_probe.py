@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run ON THE GPU BOX: the two builders side by side on a scene -- build time, node count, stack bound, nodes / triangles per ray,
+"""Run ON THE GPU BOX: the builders side by side on a scene -- build time, node count, stack bound, nodes / triangles per ray,
 Mrays/s at 1 and 8 samples per launch -- and the images must agree (same closest hits: bit-identical up to exact-t ties).
 usage: python tools/builder_probe.py [sponza|helmet|grid|figure|test]"""
 import os, sys
@@ -12,7 +12,7 @@ which = sys.argv[1] if len(sys.argv) > 1 else "sponza"
 s = {"sponza": scenes.sponza_class, "helmet": scenes.helmet_class, "grid": scenes.material_grid, "figure": scenes.skinned_figure,
      "test": lambda: scenes.test_scene(512, 256)}[which]()
 imgs = {}
-for name, b in (("lbvh", abi.BUILDER_LBVH), ("ploc", abi.BUILDER_PLOC)):
+for name, b in (("lbvh", abi.BUILDER_LBVH), ("ploc", abi.BUILDER_PLOC), ("reins", abi.BUILDER_PLOC_REINSERT)):
     r = Renderer(); r.set_accel_builder(b)
     h = s.upload(r)
     r.build_accel(); r.request_rebuild(); r.build_accel(); torch.cuda.synchronize()
@@ -42,5 +42,6 @@ for name, b in (("lbvh", abi.BUILDER_LBVH), ("ploc", abi.BUILDER_PLOC)):
     line += "  | nodes/ray %.2f tris/ray %.2f" % (c.nodes_visited / c.rays, c.tris_tested / c.rays)
     print(line)
     r.close()
-d = np.abs(imgs["lbvh"] - imgs["ploc"]).max(axis=2)
-print("texcoord debug image: pixels that differ between the builders: %.5f" % float((d > 0).mean()))
+for other in ("ploc", "reins"):
+    d = np.abs(imgs["lbvh"] - imgs[other]).max(axis=2)
+    print("texcoord debug image: pixels that differ between lbvh and %s: %.5f" % (other, float((d > 0).mean())))
