@@ -24,6 +24,9 @@
 
 namespace pt {
 
+#ifndef PT_OCC_SLOT_ORDER
+#define PT_OCC_SLOT_ORDER 0
+#endif
 #ifndef PT_STACK_LDS
 #define PT_STACK_LDS 24
 #endif
@@ -195,11 +198,21 @@ PT_DEV void trav_node_step(Trav& t, const SceneRec& sc, int* lds_stack, int* spi
     if (!ORDERED) {
         // occlusion rays accept any hit: visiting order is irrelevant, skip the sort
         int next = kTravDone;
+#if PT_OCC_SLOT_ORDER
+        // the hit children in SLOT order (the builder stores them in decreasing surface area): the first is entered, the others are
+        // pushed last-slot-first so that they pop in slot order too
+        if (key[3] != 0xffffffffu) next = c3;
+#define PT_PUSH_UNORDERED(F)                                                                                                        \
+        if (key[2] != 0xffffffffu) { if (next != kTravDone) trav_push<F>(t, lds_stack, spill, next, st); next = c2; }               \
+        if (key[1] != 0xffffffffu) { if (next != kTravDone) trav_push<F>(t, lds_stack, spill, next, st); next = c1; }               \
+        if (key[0] != 0xffffffffu) { if (next != kTravDone) trav_push<F>(t, lds_stack, spill, next, st); next = c0; }
+#else
         if (key[0] != 0xffffffffu) next = c0;
 #define PT_PUSH_UNORDERED(F)                                                                                                        \
         if (key[1] != 0xffffffffu) { if (next != kTravDone) trav_push<F>(t, lds_stack, spill, c1, st); else next = c1; }           \
         if (key[2] != 0xffffffffu) { if (next != kTravDone) trav_push<F>(t, lds_stack, spill, c2, st); else next = c2; }           \
         if (key[3] != 0xffffffffu) { if (next != kTravDone) trav_push<F>(t, lds_stack, spill, c3, st); else next = c3; }
+#endif
         if (shallow) { PT_PUSH_UNORDERED(true) } else { PT_PUSH_UNORDERED(false) }
 #undef PT_PUSH_UNORDERED
         if (next != kTravDone) t.cur = next; else trav_pop(t, lds_stack, spill);
