@@ -639,7 +639,7 @@ int pt_texture_create(pt_ctx* ctx, const uint8_t* rgba8, int width, int height, 
     ENTER(ctx);
     void* d = nullptr;
     size_t bytes = (size_t)width * height * 4;
-    HIPOK(hipMalloc(&d, bytes));
+    HIPOK(hipMalloc(&d, bytes + 4));                         // (+ 4: the sampler reads the two texels of a row as one 8-byte pair, pt_shading.h texture_taps)
     hipError_t e = hipMemcpy(d, rgba8, bytes, hipMemcpyHostToDevice);
     if (e) { hipFree(d); return ctx->fail(PT_ERR_DEVICE, std::string("pt_texture_create: ") + hipGetErrorString(e)); }
     const TextureRec rec = {(const uint32_t*)d, width, height, srgb ? 1u : 0u, 0u};

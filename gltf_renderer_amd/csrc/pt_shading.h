@@ -141,6 +141,59 @@ PT_DEV RTex load_rtex(const RTex* p) {                      // 3 x dwordx4, issu
 }
 // The four texel addresses + weights of one Texture2D.SampleLevel(sampler, uv, 0): D3D texel-centre rule.
 // TransformUv (Material.hlsli:68-88) is folded in: rows (c*sx, s*sy, ox), (-s*sx, c*sy, oy) were formed on the host in fp32.
+#ifndef PT_TEX_PAIRS
+#define PT_TEX_PAIRS 1      // the two texels of a row in ONE 8-byte load (0: four dword gathers per fetch)
+#endif
+#if PT_TEX_PAIRS
+// Both texels of a row come from one 8-byte load at the pair's base column ia = clamp(i0, 0, width - 2): element i - ia of it.  Only
+// a tap whose second column wrapped or mirrored off the pair (i0 = width - 1 with WRAP) needs its own loads, and the whole wave
+// skips those unless some lane is there.  (Textures are allocated 4 bytes long so that a width-1 texture's pair stays inside.)
+struct TexTaps { const uint32_t *p0, *p1; int i0, i1, ia, width; float w00, w10, w01, w11; uint32_t srgb; bool edge; };
+struct TexQuad { uint32_t t00, t10, t01, t11; };
+PT_DEV TexTaps texture_taps(const RTex& t, const vec2 tc[2]) {
+    const vec2 uv = (t.flags & RT_TEXCOORD1) ? tc[1] : tc[0];
+    const float tu = t.m00 * uv.x + t.m01 * uv.y + t.ox;
+    const float tv = t.m10 * uv.x + t.m11 * uv.y + t.oy;
+    const int au = (int)((t.flags >> 1) & 3u), av = (int)((t.flags >> 3) & 3u);
+    float x = finite_coord(tu * (float)t.width), y = finite_coord(tv * (float)t.height);
+    TexTaps k;
+    k.srgb = t.flags & RT_SRGB;
+    k.width = t.width;
+    int j0, j1;
+    if (t.flags & RT_POINT) {
+        k.i0 = k.i1 = wrap_addr((int)floorf(x), t.width, au); j0 = j1 = wrap_addr((int)floorf(y), t.height, av);
+        k.w00 = 1; k.w10 = k.w01 = k.w11 = 0;
+    } else {
+        x -= 0.5f; y -= 0.5f;
+        const float fx0 = floorf(x), fy0 = floorf(y);
+        const float fx = x - fx0, fy = y - fy0;
+        k.i0 = wrap_addr((int)fx0, t.width, au); k.i1 = wrap_addr((int)fx0 + 1, t.width, au);
+        j0 = wrap_addr((int)fy0, t.height, av); j1 = wrap_addr((int)fy0 + 1, t.height, av);
+        k.w00 = (1 - fx) * (1 - fy); k.w10 = fx * (1 - fy); k.w01 = (1 - fx) * fy; k.w11 = fx * fy;
+    }
+    k.ia = max(min(k.i0, t.width - 2), 0);
+    k.edge = k.i1 != k.ia && k.i1 != k.ia + 1;
+    k.p0 = t.texels + (size_t)j0 * t.width;
+    k.p1 = t.texels + (size_t)j1 * t.width;
+    return k;
+}
+PT_DEV uint2 tap_row(const TexTaps& k, int row) { return gload_u2((row ? k.p1 : k.p0) + k.ia); }
+PT_DEV TexQuad tap_quad(const TexTaps& k, const uint2 r0, const uint2 r1) {
+    TexQuad q;
+    q.t00 = k.i0 == k.ia ? r0.x : r0.y; q.t01 = k.i0 == k.ia ? r1.x : r1.y;
+    q.t10 = k.i1 == k.ia ? r0.x : r0.y; q.t11 = k.i1 == k.ia ? r1.x : r1.y;
+    if (__any(k.edge)) {
+        if (k.edge) { q.t10 = gload(k.p0 + k.i1); q.t11 = gload(k.p1 + k.i1); }
+    }
+    return q;
+}
+PT_DEV vec4 resolve_taps(const TexTaps& k, uint32_t t00, uint32_t t10, uint32_t t01, uint32_t t11, const float* srgb_lut) {
+    if (k.w10 == 0 && k.w01 == 0 && k.w11 == 0 && k.w00 == 1) return unpack_texel(t00, k.srgb, srgb_lut);      // point filter
+    return unpack_texel(t00, k.srgb, srgb_lut) * k.w00 + unpack_texel(t10, k.srgb, srgb_lut) * k.w10 +
+           unpack_texel(t01, k.srgb, srgb_lut) * k.w01 + unpack_texel(t11, k.srgb, srgb_lut) * k.w11;
+}
+PT_DEV vec4 resolve_taps(const TexTaps& k, const TexQuad& q, const float* srgb_lut) { return resolve_taps(k, q.t00, q.t10, q.t01, q.t11, srgb_lut); }
+#else
 struct TexTaps { const uint32_t *p00, *p10, *p01, *p11; float w00, w10, w01, w11; uint32_t srgb; };
 PT_DEV TexTaps texture_taps(const RTex& t, const vec2 tc[2]) {
     const vec2 uv = (t.flags & RT_TEXCOORD1) ? tc[1] : tc[0];
@@ -172,12 +225,18 @@ PT_DEV vec4 resolve_taps(const TexTaps& k, uint32_t t00, uint32_t t10, uint32_t 
     return unpack_texel(t00, k.srgb, srgb_lut) * k.w00 + unpack_texel(t10, k.srgb, srgb_lut) * k.w10 +
            unpack_texel(t01, k.srgb, srgb_lut) * k.w01 + unpack_texel(t11, k.srgb, srgb_lut) * k.w11;
 }
+#endif
 // SampleTexture (Material.hlsli:90-96) of one material slot.
 PT_DEV vec4 sample_slot(const SceneRec& sc, const RMat* m, int slot, const vec2 tc[2], unsigned& taps) {
     const RTex t = load_rtex(&m->tex[slot]);
     const TexTaps k = texture_taps(t, tc);
     taps++;
+#if PT_TEX_PAIRS
+    const uint2 r0 = tap_row(k, 0), r1 = tap_row(k, 1);
+    return resolve_taps(k, tap_quad(k, r0, r1), sc.srgb_lut);
+#else
     return resolve_taps(k, gload(k.p00), gload(k.p10), gload(k.p01), gload(k.p11), sc.srgb_lut);
+#endif
 }
 
 // ---------------------------------------------------------------- vertex fetch (PathTracer.lib.hlsl:176-302)
@@ -408,9 +467,17 @@ PT_DEV Surface get_surface(const SceneRec& sc, uint32_t flags, const RMat* m, co
     const uint32_t mid = (uint32_t)(m - sc.rmats);
     const RTex t_alb = material_slot012(sc, mid, SLOT_ALBEDO), t_nrm = material_slot012(sc, mid, SLOT_NORMAL), t_mr = material_slot012(sc, mid, SLOT_METALLIC_ROUGHNESS);
     const TexTaps k_alb = texture_taps(t_alb, a.tc), k_nrm = texture_taps(t_nrm, a.tc), k_mr = texture_taps(t_mr, a.tc);
+#if PT_TEX_PAIRS
+    const uint2 ar0 = tap_row(k_alb, 0), ar1 = tap_row(k_alb, 1), nr0 = tap_row(k_nrm, 0), nr1 = tap_row(k_nrm, 1), mr0 = tap_row(k_mr, 0), mr1 = tap_row(k_mr, 1);
+    const TexQuad qa = tap_quad(k_alb, ar0, ar1), qn = tap_quad(k_nrm, nr0, nr1), qm = tap_quad(k_mr, mr0, mr1);
+    const uint32_t a00 = qa.t00, a10 = qa.t10, a01 = qa.t01, a11 = qa.t11;
+    const uint32_t n00 = qn.t00, n10 = qn.t10, n01 = qn.t01, n11 = qn.t11;
+    const uint32_t m00 = qm.t00, m10 = qm.t10, m01 = qm.t01, m11 = qm.t11;
+#else
     const uint32_t a00 = gload(k_alb.p00), a10 = gload(k_alb.p10), a01 = gload(k_alb.p01), a11 = gload(k_alb.p11);
     const uint32_t n00 = gload(k_nrm.p00), n10 = gload(k_nrm.p10), n01 = gload(k_nrm.p01), n11 = gload(k_nrm.p11);
     const uint32_t m00 = gload(k_mr.p00), m10 = gload(k_mr.p10), m01 = gload(k_mr.p01), m11 = gload(k_mr.p11);
+#endif
     const bool b_alb = slot_bound(h.bound_mask, SLOT_ALBEDO), b_nrm = slot_bound(h.bound_mask, SLOT_NORMAL), b_mr = slot_bound(h.bound_mask, SLOT_METALLIC_ROUGHNESS);
     taps += (b_alb ? 1u : 0u) + (b_nrm ? 1u : 0u) + (b_mr ? 1u : 0u);
     vec4 bc = h.base_color_factor * a.color;                                                      // GetBaseColor, Material.hlsli:98-106

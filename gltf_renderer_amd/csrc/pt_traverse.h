@@ -27,6 +27,9 @@ namespace pt {
 #ifndef PT_OCC_SLOT_ORDER
 #define PT_OCC_SLOT_ORDER 0
 #endif
+#ifndef PT_LEAF_SINGLE
+#define PT_LEAF_SINGLE 0
+#endif
 #ifndef PT_STACK_LDS
 #define PT_STACK_LDS 24
 #endif
@@ -239,7 +242,12 @@ PT_DEV void trav_leaf_step(Trav& t, const SceneRec& sc, const int* lds_stack, co
     const uint32_t leaf = (uint32_t)~t.cur;
     const int first = (int)(leaf & kLeafFirstMask), count = (int)(leaf >> 28) + 1;
     bool stop = false;
-  for (int k = 0; k < count && !stop; k++) {
+#if PT_LEAF_SINGLE
+  const int n_here = 1;                                       // one triangle per call: a lane with more of the leaf left stays at the (shortened) leaf
+#else
+  const int n_here = count;
+#endif
+  for (int k = 0; k < n_here && !stop; k++) {
     const int tri = first + k;
     const float4* tp = (const float4*)sc.tris + (size_t)tri * 3;
     float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
@@ -283,6 +291,9 @@ PT_DEV void trav_leaf_step(Trav& t, const SceneRec& sc, const int* lds_stack, co
     }
   }
     if (stop) t.cur = kTravDone;
+#if PT_LEAF_SINGLE
+    else if (count > 1) t.cur = ~(int)(((uint32_t)(first + 1) & kLeafFirstMask) | ((uint32_t)(count - 2) << 28));
+#endif
     else trav_pop(t, lds_stack, spill);
 }
 

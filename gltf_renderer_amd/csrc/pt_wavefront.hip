@@ -30,6 +30,18 @@ extern "C" int pt_debug_read_timing(unsigned long long* out8, int reset) {
     return 0;
 }
 #endif
+#ifdef PT_UTIL_PROBE             // diagnostic build only (tools/util_probe.py): wave-iterations and active lanes of the traversal phases
+namespace pt { __device__ unsigned long long pt_util[16]; }
+extern "C" int pt_debug_read_util(unsigned long long* out16, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out16, HIP_SYMBOL(pt::pt_util), 128);
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(pt::pt_util), z, 128); }
+    return 0;
+}
+#define PT_UTIL(i, v) u_acc[i] += (v)
+#else
+#define PT_UTIL(i, v)
+#endif
 namespace pt {
 
 constexpr uint32_t kShards = 256;
@@ -56,6 +68,7 @@ struct WfBuffers {
                           // (the shadow count ping-pongs so that the fused traversal stage can zero the one the NEXT shade stage fills
                           // while it still reads the current one)
     uint32_t capacity;    // slots
+    uint32_t chunks_per_shard;   // path-state arrays: 256-slot chunks per shard (state_index)
     uint32_t seg_cap;     // entries per closest-queue segment
     uint32_t blocks_per_shard;
     uint32_t gen_region_tiles, gen_rounds;     // k_wf_generate: tiles per XCD band, workgroup-rounds to cover a band's (tile, sample) pairs
@@ -87,6 +100,23 @@ PT_DEV void nt_store(uint32_t& p, const uint32_t v) { __builtin_nontemporal_stor
 #define SLD(p) (p)
 #define SST(p, v) ((p) = (v))
 #endif
+
+// Where the state of path `slot` lives.  Generate workgroup b takes the 256-slot chunks {b, b + grid, ...} and belongs to shard b % 256,
+// so in slot order a shard's paths are 4-KB pieces 1 MB apart in each of the six state arrays, and 33 MB apart from sample to sample:
+// a shade workgroup touched hundreds of pages (0.7 UTCL1 misses per hit, profiles/r02e_memside_counters.txt).  PT_STATE_BY_SHARD stores
+// chunk c of shard s at (s * chunks_per_shard + c / 256): everything a shard reads and writes is one contiguous piece of each array.
+#ifndef PT_STATE_BY_SHARD
+#define PT_STATE_BY_SHARD 0      // (measured on MI355X: 5082 against 5081 Mrays/s, no effect -- kept as a build option)
+#endif
+PT_DEV uint32_t state_index(const WfBuffers& wf, uint32_t slot) {
+#if PT_STATE_BY_SHARD
+    const uint32_t c = slot >> 8;
+    return (((c & (kShards - 1u)) * wf.chunks_per_shard + (c >> 8)) << 8) | (slot & 255u);
+#else
+    return slot;
+#endif
+}
+#define SIDX(s) state_index(wf, (s))
 
 // wave64 ballot compaction into a shard counter: lanes with `pred` get consecutive indices; one atomic per wave.
 PT_DEV uint32_t queue_push(uint32_t* counter, bool pred) {
@@ -167,10 +197,10 @@ __global__ __launch_bounds__(kBlock) void k_wf_generate(FrameConstants fc, WfBuf
             const size_t e = (size_t)sv.shard * wf.seg_cap + idx;
             QST(wf.ray_o[0][e], make_float4(ray.o.x, ray.o.y, ray.o.z, ray.tmax));
             QST(wf.ray_d[0][e], make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(slot)));
-            SST(wf.L[slot], make_float4(0, 0, 0, 0));
-            SST(wf.beta_pdf[slot], make_float4(1, 1, 1, 0));
-            SST(wf.thr_misc[slot], make_float4(1, 1, 1, __uint_as_float((uint32_t)rc)));
-            SST(wf.pflags[slot], 0);
+            SST(wf.L[SIDX(slot)], make_float4(0, 0, 0, 0));
+            SST(wf.beta_pdf[SIDX(slot)], make_float4(1, 1, 1, 0));
+            SST(wf.thr_misc[SIDX(slot)], make_float4(1, 1, 1, __uint_as_float((uint32_t)rc)));
+            SST(wf.pflags[SIDX(slot)], 0);
             n_primary++;
         }
     }
@@ -197,6 +227,9 @@ PT_DEV void trace_persistent(const SceneRec& sc, const WfBuffers& wf, int* my_st
     t.cur = kTravDone; t.sp = 0;
     bool has = false, exhausted = (n == 0);
     uint32_t entry = 0, slot_bits = 0;
+#ifdef PT_UTIL_PROBE
+    unsigned long long u_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // wave-level: [0] node iterations [1] lanes stepping [2] leaf iterations [3] lanes testing [4] refills [5] lanes refilled [6] lanes holding a ray, summed over node iterations
+#endif
     for (;;) {
         // ---- refill idle lanes from the shard queue: ballot + one atomic per wave
         const unsigned long long idle = __ballot(!has);
@@ -206,6 +239,7 @@ PT_DEV void trace_persistent(const SceneRec& sc, const WfBuffers& wf, int* my_st
             uint32_t first = 0;
             if ((int)lane == leader) first = atomicAdd(head, nidle);
             first = __shfl(first, leader, 64);
+            PT_UTIL(4, 1); PT_UTIL(5, min(nidle, first < n ? n - first : 0u));
             if (!has) {
                 const uint32_t i = first + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
                 if (i < n) {
@@ -242,9 +276,13 @@ PT_DEV void trace_persistent(const SceneRec& sc, const WfBuffers& wf, int* my_st
             const unsigned long long at_node = __ballot(has && t.cur >= 0);
             if (at_node == 0) break;
             if (PT_NODE_MIN > 1 && (int)__popcll(at_node) < PT_NODE_MIN && __ballot(has && t.cur < 0 && t.cur != kTravDone) != 0) break;
+            PT_UTIL(0, 1); PT_UTIL(1, __popcll(at_node)); PT_UTIL(6, __popcll(__ballot(has)));
             if (has && t.cur >= 0) trav_node_step<COUNT, MODE == 0>(t, sc, my_stack, spill, st);
         }
         // ---- leaf phase
+#ifdef PT_UTIL_PROBE
+        { const unsigned long long at_leaf = __ballot(has && t.cur != kTravDone && t.cur < 0); if (at_leaf) { PT_UTIL(2, 1); PT_UTIL(3, __popcll(at_leaf)); } }
+#endif
         if (has && t.cur != kTravDone && t.cur < 0) trav_leaf_step<COUNT>(t, sc, my_stack, spill, st);
         // ---- retire finished rays
         if (has && t.cur == kTravDone) {
@@ -254,12 +292,15 @@ PT_DEV void trace_persistent(const SceneRec& sc, const WfBuffers& wf, int* my_st
             } else {
                 const float tr = t.committed ? t.transmission : 1.0f;                                              // ShadowMiss :1081-1085
                 const uint32_t slot = slot_bits & 0x7fffffffu;
-                float* w = (slot_bits >> 31) ? &wf.pend_light[slot].w : &wf.pend_env[slot].w;
+                float* w = (slot_bits >> 31) ? &wf.pend_light[SIDX(slot)].w : &wf.pend_env[SIDX(slot)].w;
                 *w = tr;
             }
             has = false;
         }
     }
+#ifdef PT_UTIL_PROBE
+    if (lane == 0) for (int k = 0; k < 7; k++) atomicAdd(&pt_util[MODE * 8 + k], u_acc[k]);
+#endif
 }
 
 #ifndef PT_TRACE_WAVES
@@ -309,8 +350,8 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_traverse(SceneRec
 // Both pending records are fetched whatever the flags say (the slots always exist): three loads in one round trip instead of
 // the flags first and the records behind them.
 PT_DEV void apply_pending(const WfBuffers& wf, uint32_t slot, vec3& L) {
-    const uint32_t pf = SLD(wf.pflags[slot]);
-    const float4 pe = SLD(wf.pend_env[slot]), pl = SLD(wf.pend_light[slot]);
+    const uint32_t pf = SLD(wf.pflags[SIDX(slot)]);
+    const float4 pe = SLD(wf.pend_env[SIDX(slot)]), pl = SLD(wf.pend_light[SIDX(slot)]);
     if ((pf & 1u) && pe.w > 0.0f) L += v3(pe.x, pe.y, pe.z) * pe.w;
     if ((pf & 2u) && pl.w > 0.0f) L += v3(pl.x, pl.y, pl.z) * pl.w;
 }
@@ -358,11 +399,11 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
             // the hit's shading packet depends on the queue entry only, like the path state below: one round trip for both
             const uint32_t hb = __float_as_uint(h.w);
             const RawPacket packet = load_shade_packet_raw(sc.shade + (hb == kMissTri ? 0u : (hb & 0x7fffffffu)));
-            const float4 bp = SLD(wf.beta_pdf[slot]), tm = SLD(wf.thr_misc[slot]);
+            const float4 bp = SLD(wf.beta_pdf[SIDX(slot)]), tm = SLD(wf.thr_misc[SIDX(slot)]);
             const uint32_t misc = __float_as_uint(tm.w);
             ps.beta = v3(bp.x, bp.y, bp.z); ps.prev_pdf = bp.w; ps.thr = v3(tm.x, tm.y, tm.z);
             ps.rc = (int)(misc & 0xffffu); ps.bounce = (int)((misc >> 16) & 0x7fffu); ps.prev_mis = (misc >> 31) != 0;
-            float4 Lq = SLD(wf.L[slot]);
+            float4 Lq = SLD(wf.L[SIDX(slot)]);
             vec3 L = v3(Lq.x, Lq.y, Lq.z);
             apply_pending(wf, slot, L);
             uint32_t pf = 0;
@@ -379,12 +420,12 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
                 n_shadow += fu.counted_shadow;
                 if (!done) {
                     push_env = fu.q_env; push_light = fu.q_light; push_bounce = fu.q_bounce;
-                    if (push_env) { pf |= 1u; SST(wf.pend_env[slot], make_float4(fu.pend_env.x, fu.pend_env.y, fu.pend_env.z, 0.0f)); }
-                    if (push_light) { pf |= 2u; SST(wf.pend_light[slot], make_float4(fu.pend_light.x, fu.pend_light.y, fu.pend_light.z, 0.0f)); }
+                    if (push_env) { pf |= 1u; SST(wf.pend_env[SIDX(slot)], make_float4(fu.pend_env.x, fu.pend_env.y, fu.pend_env.z, 0.0f)); }
+                    if (push_light) { pf |= 2u; SST(wf.pend_light[SIDX(slot)], make_float4(fu.pend_light.x, fu.pend_light.y, fu.pend_light.z, 0.0f)); }
                 }
             }
-            SST(wf.L[slot], make_float4(L.x, L.y, L.z, 0));
-            SST(wf.pflags[slot], pf);
+            SST(wf.L[SIDX(slot)], make_float4(L.x, L.y, L.z, 0));
+            SST(wf.pflags[SIDX(slot)], pf);
         }
         // ---- compaction into this shard's shadow segment and next closest-ray segment (wave-uniform control flow)
         const uint32_t ie = queue_push(cnt_shadow, push_env);
@@ -403,9 +444,9 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
         if (push_bounce) {                                                                           // TraceBounceRay :669-678
             QST(wf.ray_o[nxt][base + ib], make_float4(fu.b_o.x, fu.b_o.y, fu.b_o.z, fc.max_ray_length));
             QST(wf.ray_d[nxt][base + ib], make_float4(fu.b_d.x, fu.b_d.y, fu.b_d.z, __uint_as_float(slot)));
-            SST(wf.beta_pdf[slot], make_float4(fu.b_beta.x, fu.b_beta.y, fu.b_beta.z, fu.b_pdf));
+            SST(wf.beta_pdf[SIDX(slot)], make_float4(fu.b_beta.x, fu.b_beta.y, fu.b_beta.z, fu.b_pdf));
             const uint32_t misc = ((uint32_t)ps.rc & 0xffffu) | ((uint32_t)(ps.bounce + 1) << 16) | (fu.b_mis ? 0x80000000u : 0u);
-            SST(wf.thr_misc[slot], make_float4(fu.b_thr.x, fu.b_thr.y, fu.b_thr.z, __uint_as_float(misc)));
+            SST(wf.thr_misc[SIDX(slot)], make_float4(fu.b_thr.x, fu.b_thr.y, fu.b_thr.z, __uint_as_float(misc)));
             n_bounce++;
         }
     }
@@ -436,7 +477,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_resolve(FrameConstants fc, WfBuff
     if (accumulate && fc.accumulated_frames != 0) pixel = *outp;
     for (uint32_t k = 0; k < fc.spp; k++) {
         const uint32_t slot = k * fc.pixel_slots + pslot;
-        float4 Lq = SLD(wf.L[slot]);
+        float4 Lq = SLD(wf.L[SIDX(slot)]);
         vec3 L = v3(Lq.x, Lq.y, Lq.z);
         apply_pending(wf, slot, L);
         L = sanitize_sample(fc, L);
@@ -468,16 +509,22 @@ static uint32_t seg_cap_for(const FrameConstants& fc, uint32_t blocks_per_shard)
     return gen_rounds_for(fc, blocks_per_shard) * blocks_per_shard * kBlock;
 }
 
+// entries of each path-state array: whole 256-slot chunks, the same number for every shard (state_index)
+static uint32_t chunks_per_shard_for(size_t slots) { return (uint32_t)(((slots + kBlock - 1) / kBlock + kShards - 1) / kShards); }
+static size_t state_slots_for(size_t slots) { return (size_t)chunks_per_shard_for(slots) * kShards * kBlock; }
+
 size_t wavefront_workspace_bytes(const FrameConstants& fc, int stage_blocks) {
     const uint32_t bps = blocks_per_shard_for(stage_blocks);
-    const size_t slots = (size_t)fc.my_tiles * kBlock * fc.spp;
+    const size_t slots = state_slots_for((size_t)fc.my_tiles * kBlock * fc.spp);
     const size_t q = (size_t)kShards * seg_cap_for(fc, bps);
     return slots * (5 * 16 + 4) + q * (4 * 16 + 16 + 2 * 2 * 16) + 6 * kShards * kCounterStride * 4 + 32 * 256;
 }
 
 static WfBuffers carve(void* base, const FrameConstants& fc, int stage_blocks) {
     const uint32_t slots = fc.my_tiles * kBlock * fc.spp;
+    const size_t state_slots = state_slots_for(slots);
     WfBuffers wf;
+    wf.chunks_per_shard = chunks_per_shard_for(slots);
     char* p = (char*)base;
     auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
     wf.blocks_per_shard = blocks_per_shard_for(stage_blocks);
@@ -486,12 +533,12 @@ static WfBuffers carve(void* base, const FrameConstants& fc, int stage_blocks) {
     wf.gen_rounds = gen_rounds_for(fc, wf.blocks_per_shard);
     const size_t q = (size_t)kShards * wf.seg_cap;
     for (int k = 0; k < 6; k++) wf.cnt[k] = (uint32_t*)take((size_t)kShards * kCounterStride * 4);
-    wf.L = (float4*)take((size_t)slots * 16);
-    wf.beta_pdf = (float4*)take((size_t)slots * 16);
-    wf.thr_misc = (float4*)take((size_t)slots * 16);
-    wf.pend_env = (float4*)take((size_t)slots * 16);
-    wf.pend_light = (float4*)take((size_t)slots * 16);
-    wf.pflags = (uint32_t*)take((size_t)slots * 4);
+    wf.L = (float4*)take(state_slots * 16);
+    wf.beta_pdf = (float4*)take(state_slots * 16);
+    wf.thr_misc = (float4*)take(state_slots * 16);
+    wf.pend_env = (float4*)take(state_slots * 16);
+    wf.pend_light = (float4*)take(state_slots * 16);
+    wf.pflags = (uint32_t*)take(state_slots * 4);
     for (int k = 0; k < 2; k++) { wf.ray_o[k] = (float4*)take(q * 16); wf.ray_d[k] = (float4*)take(q * 16); }
     wf.hit = (float4*)take(q * 16);
     wf.sh_o = (float4*)take(q * 2 * 16);
@@ -545,6 +592,9 @@ hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4
     // probability to its floor): a launch sized for the full queue then mostly starts workgroups that find nothing and, in the shade
     // stage, would stage 67 KB of tables for it.  The grid of a bounce follows the EXPECTED queue (a quarter of the paths per bounce
     // beyond min_bounces + 1); only speed depends on the guess -- any multiple of kShards workgroups walks the whole queue.
+    // tuning aid (tools/overlap_probe.py): MIPT_SHADE_BPS / MIPT_TRACE_BPS = workgroups per shard of the shade / traversal launches
+    static const int env_shade_bps = getenv("MIPT_SHADE_BPS") ? atoi(getenv("MIPT_SHADE_BPS")) : 0;
+    static const int env_trace_bps = getenv("MIPT_TRACE_BPS") ? atoi(getenv("MIPT_TRACE_BPS")) : 0;
     auto grid_of = [&](int b) -> dim3 {
         uint32_t bps = wf.blocks_per_shard;
         if (b > fc.min_bounces + 1) {
@@ -558,6 +608,8 @@ hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4
 #define PT_GRID(b) grid_of(b)
 #define PT_WF(b) wf_for(b)
     auto wf_for = [&](int b) { WfBuffers w = wf; w.blocks_per_shard = grid_of(b).x / kShards; return w; };
+    auto cap = [&](dim3 g, int env) { if (env > 0 && (uint32_t)env * kShards < g.x) g.x = (uint32_t)env * kShards; return g; };
+    auto wf_of = [&](dim3 g) { WfBuffers w = wf; w.blocks_per_shard = g.x / kShards; return w; };
 #else
 #define PT_GRID(b) stage
 #define PT_WF(b) wf
@@ -567,22 +619,35 @@ hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4
     {
         uint32_t rf, rmask;
         ray_flags(0, rf, rmask);
+#if PT_LATE_GRID
+        const dim3 g0 = cap(stage, env_trace_bps);
+        if (count) hipLaunchKernelGGL(k_wf_trace<true>, g0, block, 0, stream, sc, wf_of(g0), 0, 0, rf, rmask, counters);
+        else hipLaunchKernelGGL(k_wf_trace<false>, g0, block, 0, stream, sc, wf_of(g0), 0, 0, rf, rmask, counters);
+#else
         if (count) hipLaunchKernelGGL(k_wf_trace<true>, stage, block, 0, stream, sc, wf, 0, 0, rf, rmask, counters);
         else hipLaunchKernelGGL(k_wf_trace<false>, stage, block, 0, stream, sc, wf, 0, 0, rf, rmask, counters);
+#endif
         mark(STAGE_TRACE);
     }
     for (int b = 0; b < iterations; b++) {
         const int cur = b & 1;
-        hipLaunchKernelGGL(k_wf_shade, PT_GRID(b), block, 0, stream, sc, fc, PT_WF(b), cur, b, counters);
+#if PT_LATE_GRID
+        const dim3 gs = cap(grid_of(b), env_shade_bps), gt = cap(grid_of(b), env_trace_bps);
+        const WfBuffers ws = wf_of(gs), wt = wf_of(gt);
+#else
+        const dim3 gs = stage, gt = stage;
+        const WfBuffers& ws = wf; const WfBuffers& wt = wf;
+#endif
+        hipLaunchKernelGGL(k_wf_shade, gs, block, 0, stream, sc, fc, ws, cur, b, counters);
         mark(STAGE_SHADE);
         uint32_t rf, rmask;
         ray_flags(b + 1, rf, rmask);
         if (b + 1 < iterations) {
-            if (count) hipLaunchKernelGGL(k_wf_traverse<true>, PT_GRID(b), block, 0, stream, sc, PT_WF(b), cur ^ 1, b, rf, rmask, flags, counters);
-            else hipLaunchKernelGGL(k_wf_traverse<false>, PT_GRID(b), block, 0, stream, sc, PT_WF(b), cur ^ 1, b, rf, rmask, flags, counters);
+            if (count) hipLaunchKernelGGL(k_wf_traverse<true>, gt, block, 0, stream, sc, wt, cur ^ 1, b, rf, rmask, flags, counters);
+            else hipLaunchKernelGGL(k_wf_traverse<false>, gt, block, 0, stream, sc, wt, cur ^ 1, b, rf, rmask, flags, counters);
         } else {                                                                                      // the last vertex pushes no bounce ray
-            if (count) hipLaunchKernelGGL(k_wf_shadow<true>, PT_GRID(b), block, 0, stream, sc, PT_WF(b), b, flags, counters);
-            else hipLaunchKernelGGL(k_wf_shadow<false>, PT_GRID(b), block, 0, stream, sc, PT_WF(b), b, flags, counters);
+            if (count) hipLaunchKernelGGL(k_wf_shadow<true>, gt, block, 0, stream, sc, wt, b, flags, counters);
+            else hipLaunchKernelGGL(k_wf_shadow<false>, gt, block, 0, stream, sc, wt, b, flags, counters);
         }
         mark(STAGE_SHADOW);
     }
