@@ -171,6 +171,9 @@ PT_DEV void trav_node_step(Trav& t, const SceneRec& sc, int* lds_stack, int* spi
     const float4 hd = np[0], chf = np[1], qxy = np[2];
     const float2 qz = *(const float2*)(np + 3);
     if (COUNT) st.nodes++;
+#ifdef PT_PROBE_VALU          // diagnostic build only: PT_PROBE_VALU extra dependent VALU instructions per node step
+    { float x = t.tmin; _Pragma("unroll") for (int i = 0; i < PT_PROBE_VALU; i++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(x)); if (x == 123.456f) st.overflow++; }
+#endif
     const float limit = t.all_candidates ? t.tmax : t.best.t;
     const int c0 = __float_as_int(chf.x), c1 = __float_as_int(chf.y), c2 = __float_as_int(chf.z), c3 = __float_as_int(chf.w);
     // dequantise the four boxes (pt_types.h Bvh4Node): plane = origin + q * 2^(exp - 127), byte k of each word = child k

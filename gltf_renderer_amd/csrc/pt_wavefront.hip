@@ -47,6 +47,7 @@ namespace pt {
 constexpr uint32_t kShards = 256;
 constexpr uint32_t kMissTri = 0x7fffffffu;
 constexpr uint32_t kCounterStride = 16;      // one 64-B line per shard counter
+constexpr int kCounterArrays = 7;
 
 struct WfBuffers {
     // per slot (one path per pixel of this rank)
@@ -63,10 +64,10 @@ struct WfBuffers {
     // shadow queue, kShards segments of 2 * seg_cap entries: (o.xyz, bits: slot | is_light << 31), (d.xyz, tmax)
     float4* sh_o;
     float4* sh_d;
-    uint32_t* cnt[6];     // per shard (stride kCounterStride): entry counts of closest queue 0, closest queue 1, shadow queue (even bounces);
+    uint32_t* cnt[7];     // per shard (stride kCounterStride): entry counts of closest queue 0, closest queue 1, shadow queue (even bounces);
                           // [3], [4]: dynamic-fetch heads of the closest / shadow trace stages; [5]: shadow-queue count of odd bounces
                           // (the shadow count ping-pongs so that the fused traversal stage can zero the one the NEXT shade stage fills
-                          // while it still reads the current one)
+                          // while it still reads the current one); [6]: dynamic-fetch head of the shade stage
     uint32_t capacity;    // slots
     uint32_t chunks_per_shard;   // path-state arrays: 256-slot chunks per shard (state_index)
     uint32_t seg_cap;     // entries per closest-queue segment
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_trace(SceneRec sc
     stage_luts(sc);
     const ShardView sv = shard_view(wf);
     // member 0 of each shard zeroes the counters the following shade stage fills
-    if (sv.member == 0 && threadIdx.x == 0) { wf.cnt[cur ^ 1][sv.shard * kCounterStride] = 0; wf.cnt[shadow_counter(bounce)][sv.shard * kCounterStride] = 0; }
+    if (sv.member == 0 && threadIdx.x == 0) { wf.cnt[cur ^ 1][sv.shard * kCounterStride] = 0; wf.cnt[shadow_counter(bounce)][sv.shard * kCounterStride] = 0; wf.cnt[6][sv.shard * kCounterStride] = 0; }
     LaneStats st = {0, 0, 0, 0};
     trace_persistent<COUNT, 0>(sc, wf, s_stack + threadIdx.x, sv, cur, rf, rmask, 0, st);
     if (COUNT) flush_counters(counters, threadIdx.x & 63, 0, 0, 0, 0, st);
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_traverse(SceneRec
     __shared__ int s_stack[kStackLds * kBlock];
     stage_luts(sc);
     const ShardView sv = shard_view(wf);
-    if (sv.member == 0 && threadIdx.x == 0) { wf.cnt[nxt ^ 1][sv.shard * kCounterStride] = 0; wf.cnt[shadow_counter(bounce + 1)][sv.shard * kCounterStride] = 0; }
+    if (sv.member == 0 && threadIdx.x == 0) { wf.cnt[nxt ^ 1][sv.shard * kCounterStride] = 0; wf.cnt[shadow_counter(bounce + 1)][sv.shard * kCounterStride] = 0; wf.cnt[6][sv.shard * kCounterStride] = 0; }
     LaneStats st_shadow = {0, 0, 0, 0}, st = {0, 0, 0, 0};
     trace_persistent<COUNT, 1>(sc, wf, s_stack + threadIdx.x, sv, shadow_counter(bounce), 0, 0xff, flags, st_shadow);
     trace_persistent<COUNT, 0>(sc, wf, s_stack + threadIdx.x, sv, nxt, rf, rmask, 0, st);
@@ -356,6 +357,9 @@ PT_DEV void apply_pending(const WfBuffers& wf, uint32_t slot, vec3& L) {
     if ((pf & 2u) && pl.w > 0.0f) L += v3(pl.x, pl.y, pl.z) * pl.w;
 }
 
+#ifndef PT_SHADE_DYNAMIC
+#define PT_SHADE_DYNAMIC 1    // shade-stage waves pull 64-entry chunks from the shard's head counter (0: static rounds over the grid's stride)
+#endif
 #ifndef PT_SHADE_WAVES
 #define PT_SHADE_WAVES 2      // waves per SIMD the register allocator must leave room for (2 -> <= 256 VGPR+AGPR)
 #endif
@@ -381,10 +385,27 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
     if (sv.member == 0 && threadIdx.x == 0) { wf.cnt[3][sv.shard * kCounterStride] = 0; wf.cnt[4][sv.shard * kCounterStride] = 0; }
     unsigned n_bounce = 0, n_shadow = 0, n_hits = 0;
     LaneStats st = {0, 0, 0, 0};
+#if PT_SHADE_DYNAMIC
+    // Every WAVE pulls the next 64 entries of its shard's queue from the shard's head counter (one atomic per wave and chunk, the next
+    // chunk requested before the current one is shaded, so its round trip is hidden).  Hits differ in cost and a queue is rarely a
+    // multiple of the grid's stride: with static rounds a launch ran as long as the workgroups that had one chunk more (a 1-spp
+    // 1080p frame: 5.27 rounds' worth of work took 6 rounds).
+    uint32_t* shade_head = wf.cnt[6] + sv.shard * kCounterStride;
+    const uint32_t lane64 = threadIdx.x & 63u;
+    uint32_t chunk = 0;
+    if (lane64 == 0) chunk = atomicAdd(shade_head, 64u);
+    chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
+    while (chunk < n) {
+        uint32_t next_chunk = 0;
+        if (lane64 == 0) next_chunk = atomicAdd(shade_head, 64u);
+        const uint32_t i = chunk + lane64;
+        const bool active = i < n;
+#else
     const uint32_t rounds = (n + sv.stride - 1) / sv.stride;      // uniform per workgroup: ballots inside stay wave-uniform
     for (uint32_t rnd = 0; rnd < rounds; rnd++) {
         const uint32_t i = rnd * sv.stride + sv.member * kBlock + threadIdx.x;
         const bool active = i < n;
+#endif
         bool push_env = false, push_light = false, push_bounce = false;
         Followups fu;
         fu.q_env = fu.q_light = fu.q_bounce = false;
@@ -449,6 +470,9 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
             SST(wf.thr_misc[SIDX(slot)], make_float4(fu.b_thr.x, fu.b_thr.y, fu.b_thr.z, __uint_as_float(misc)));
             n_bounce++;
         }
+#if PT_SHADE_DYNAMIC
+        chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_chunk);
+#endif
     }
     flush_counters(counters, threadIdx.x & 63, 0, n_bounce, n_shadow, n_hits, st);
 }
@@ -517,7 +541,7 @@ size_t wavefront_workspace_bytes(const FrameConstants& fc, int stage_blocks) {
     const uint32_t bps = blocks_per_shard_for(stage_blocks);
     const size_t slots = state_slots_for((size_t)fc.my_tiles * kBlock * fc.spp);
     const size_t q = (size_t)kShards * seg_cap_for(fc, bps);
-    return slots * (5 * 16 + 4) + q * (4 * 16 + 16 + 2 * 2 * 16) + 6 * kShards * kCounterStride * 4 + 32 * 256;
+    return slots * (5 * 16 + 4) + q * (4 * 16 + 16 + 2 * 2 * 16) + kCounterArrays * kShards * kCounterStride * 4 + 32 * 256;
 }
 
 static WfBuffers carve(void* base, const FrameConstants& fc, int stage_blocks) {
@@ -532,7 +556,7 @@ static WfBuffers carve(void* base, const FrameConstants& fc, int stage_blocks) {
     wf.gen_region_tiles = gen_region_tiles_for(fc);
     wf.gen_rounds = gen_rounds_for(fc, wf.blocks_per_shard);
     const size_t q = (size_t)kShards * wf.seg_cap;
-    for (int k = 0; k < 6; k++) wf.cnt[k] = (uint32_t*)take((size_t)kShards * kCounterStride * 4);
+    for (int k = 0; k < kCounterArrays; k++) wf.cnt[k] = (uint32_t*)take((size_t)kShards * kCounterStride * 4);
     wf.L = (float4*)take(state_slots * 16);
     wf.beta_pdf = (float4*)take(state_slots * 16);
     wf.thr_misc = (float4*)take(state_slots * 16);
@@ -571,7 +595,7 @@ hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4
     };
     const uint32_t slots = fc.my_tiles * kBlock * fc.spp;
     WfBuffers wf = carve(workspace, fc, stage_blocks);
-    hipError_t e = hipMemsetAsync(wf.cnt[0], 0, (size_t)6 * kShards * kCounterStride * 4, stream);     // the six counter arrays are contiguous
+    hipError_t e = hipMemsetAsync(wf.cnt[0], 0, (size_t)kCounterArrays * kShards * kCounterStride * 4, stream);     // the counter arrays are contiguous
     if (e) return e;
     const dim3 block(kBlock), full(fc.my_tiles), stage(kShards * wf.blocks_per_shard);
     if (timers) { hipEvent_t ev = event_at(0); if (ev) hipEventRecord(ev, stream); else timers = nullptr; }

@@ -37,13 +37,15 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
-    if not os.path.exists(LIB_PATH):
+    # MIPT_LIBRARY: a tuning build of the same library (tools/build_variant.sh) for A/B runs; never another implementation
+    lib_path = os.environ.get("MIPT_LIBRARY") or LIB_PATH
+    if not os.path.exists(lib_path):
         raise MiptError("libmipt.so not found at %s: build it with `make -C gltf_renderer_amd/csrc` "
-                        "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+                        "(or __graft_entry__.build()); there is no CPU fallback" % lib_path)
     # One HIP runtime per process: PyTorch ships its own libamdhip64, and whichever copy is mapped first serves both.  Import
     # torch BEFORE libmipt.so so that it is torch's copy (loading /opt/rocm's first makes later device queries fail).
     import torch  # noqa: F401
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(lib_path)
     missing = [s for s in EXPORTS if not hasattr(L, s)]
     if missing:
         raise MiptError("libmipt.so lacks symbols declared in include/mipt.h: %s" % missing)
