@@ -51,6 +51,10 @@ struct pt_ctx {
     std::vector<SamplerRec> samplers;
     BufferRec* d_buffers = nullptr; size_t d_buffers_cap = 0; bool buffers_dirty = true;   // device copy: BVH build only
     uint32_t* d_white = nullptr;                                   // 1x1 white texel behind every unbound material slot
+    // interleaved albedo / normal / metal-rough texels of the materials whose three textures share one footprint (pt_types.h RM_TRIO),
+    // keyed by the three texel pointers (nullptr = slot unbound); owned here, rebuilt / released by pt_scene_set_materials
+    struct TrioRec { const uint32_t *a, *n, *m; uint4* ptr; };
+    std::vector<TrioRec> trios;
 
     // ---- per-frame arrays (Renderer::GatherMaterials / GatherLights)
     RMat* d_rmats = nullptr; int n_materials = 0; size_t rmats_cap = 0;    // resolved on the host in pt_scene_set_materials
@@ -554,6 +558,7 @@ void pt_destroy(pt_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     for (auto& b : ctx->buffers) hipFree((void*)b.ptr);
     for (auto& t : ctx->textures) hipFree((void*)t.texels);
+    for (auto& t : ctx->trios) hipFree((void*)t.ptr);
     for (auto* e : ctx->envs) if (e) { env_free(*e); delete e; }
     hipFree(ctx->d_buffers); hipFree(ctx->d_white); hipFree(ctx->d_rmats); hipFree(ctx->d_lights);
     hipFree(ctx->d_instances); hipFree(ctx->d_nodes); hipFree(ctx->d_tris); hipFree(ctx->d_shade); hipFree(ctx->d_sheen); hipFree(ctx->d_srgb); hipFree(ctx->d_tangent_lut); hipFree(ctx->d_counters);
@@ -671,6 +676,12 @@ int pt_sampler_create(pt_ctx* ctx, const pt_sampler_desc* d, int* handle_out) {
     return PT_OK;
 }
 
+// {albedo, normal, metal-rough, -} per texel from the three RGBA8 images of one size (an unbound one reads as white, like d_white)
+__global__ void k_trio_interleave(uint4* __restrict__ dst, const uint32_t* __restrict__ a, const uint32_t* __restrict__ n, const uint32_t* __restrict__ m, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = make_uint4(a[i], n ? n[i] : 0xffffffffu, m ? m[i] : 0xffffffffu, 0xffffffffu);
+}
+
 int pt_scene_set_materials(pt_ctx* ctx, const pt_material* m, int count) {
     if (!ctx || (count > 0 && !m) || count < 0) return PT_ERR_INVALID_ARGUMENT;
     // the instance table's material ids index this table: a shorter table must not leave one dangling (device reads of rmats[] and
@@ -729,10 +740,61 @@ int pt_scene_set_materials(pt_ctx* ctx, const pt_material* m, int count) {
             r.bound_mask |= 1u << k;
         }
     }
+    // Interleaved footprint (RM_TRIO): the albedo texture plus whichever of the normal and metal-rough textures are bound, when they
+    // have its size, sampler state, UV set and UV transform -- the three bilinear footprints are then the same four texels, and the
+    // shade stage reads them from one 16-B-a-texel copy (two cache lines a hit instead of six).  Same texels, same weights: images are
+    // bit-identical either way (MIPT_TEXTURE_INTERLEAVE=0 keeps every material on the general path; tested).
+    const char* env_trio = getenv("MIPT_TEXTURE_INTERLEAVE");
+    const bool use_trio = !(env_trio && env_trio[0] == '0');
+    std::vector<char> trio_live(ctx->trios.size(), 0);
+    for (int i = 0; i < count && use_trio; i++) {
+        RMat& r = rm[i];
+        const RTex& A = r.tex[SLOT_ALBEDO];
+        const RTex& N = r.tex[SLOT_NORMAL];
+        const RTex& M = r.tex[SLOT_METALLIC_ROUGHNESS];
+        const bool ba = (r.bound_mask >> SLOT_ALBEDO) & 1u, bn = (r.bound_mask >> SLOT_NORMAL) & 1u, bm = (r.bound_mask >> SLOT_METALLIC_ROUGHNESS) & 1u;
+        auto same_footprint = [&](const RTex& t) {
+            return t.width == A.width && t.height == A.height && ((t.flags ^ A.flags) & ~(uint32_t)RT_SRGB) == 0 && memcmp(&t.m00, &A.m00, 6 * sizeof(float)) == 0;
+        };
+        if (!ba || !(bn || bm) || (bn && !same_footprint(N)) || (bm && !same_footprint(M))) continue;
+        const uint32_t* kn = bn ? N.texels : nullptr;
+        const uint32_t* km = bm ? M.texels : nullptr;
+        size_t at = ctx->trios.size();
+        for (size_t k = 0; k < ctx->trios.size(); k++)
+            if (ctx->trios[k].a == A.texels && ctx->trios[k].n == kn && ctx->trios[k].m == km) { at = k; break; }
+        if (at == ctx->trios.size()) {
+            const size_t texels = (size_t)A.width * A.height;
+            uint4* d = nullptr;
+            if (hipMalloc((void**)&d, texels * 16 + 32) != hipSuccess) { (void)hipGetLastError(); continue; }     // no room: this material stays on the general path
+            hipLaunchKernelGGL(k_trio_interleave, dim3((unsigned)((texels + 255) / 256)), dim3(256), 0, ctx->stream, d, A.texels, kn, km, texels);
+            HIPOK(hipMemsetAsync((char*)d + texels * 16, 0xff, 32, ctx->stream));
+            ctx->trios.push_back({A.texels, kn, km, d});
+            trio_live.push_back(0);
+        }
+        trio_live[at] = 1;
+        r.trio = ctx->trios[at].ptr;
+        r.bound_mask |= RM_TRIO | ((bn && (N.flags & RT_SRGB)) ? RM_TRIO_SRGB_N : 0u) | ((bm && (M.flags & RT_SRGB)) ? RM_TRIO_SRGB_M : 0u);
+    }
     HIPOK(upload_table(ctx, ctx->d_rmats, ctx->rmats_cap, rm));
     ctx->rmats_host.swap(rm);
     ctx->n_materials = count;
+    // copies the new table no longer names: enqueued frames may still read them, so drain the stream first (a scene change, not a per-frame event)
+    bool any_dead = false;
+    for (char l : trio_live) any_dead |= !l;
+    if (any_dead) {
+        HIPOK(hipStreamSynchronize(ctx->stream));
+        std::vector<pt_ctx::TrioRec> keep;
+        for (size_t k = 0; k < ctx->trios.size(); k++) { if (trio_live[k]) keep.push_back(ctx->trios[k]); else hipFree((void*)ctx->trios[k].ptr); }
+        ctx->trios.swap(keep);
+    }
     return PT_OK;
+}
+
+// diagnostic (not part of include/mipt.h): how many materials of the current table read the interleaved footprint
+extern "C" int pt_debug_interleaved_materials(const pt_ctx* ctx) {
+    int n = 0;
+    if (ctx) for (const RMat& r : ctx->rmats_host) n += (r.bound_mask & RM_TRIO) ? 1 : 0;
+    return n;
 }
 
 int pt_scene_set_lights(pt_ctx* ctx, const pt_light* l, int count) {

@@ -24,10 +24,12 @@ struct vec4 { float x, y, z, w; };
 typedef float pt_f4n __attribute__((ext_vector_type(4)));
 typedef float pt_f2n __attribute__((ext_vector_type(2)));
 typedef uint32_t pt_u2n __attribute__((ext_vector_type(2)));
+typedef uint32_t pt_u4n __attribute__((ext_vector_type(4)));
 template <class T> PT_DEV T gload(const T* p) { return *(const PT_GLOBAL T*)p; }                     // scalar types only
 PT_DEV float4 gload_f4(const void* p) { pt_f4n v = *(const PT_GLOBAL pt_f4n*)p; return make_float4(v.x, v.y, v.z, v.w); }
 PT_DEV float2 gload_f2(const void* p) { pt_f2n v = *(const PT_GLOBAL pt_f2n*)p; return make_float2(v.x, v.y); }
 PT_DEV uint2 gload_u2(const void* p) { pt_u2n v = *(const PT_GLOBAL pt_u2n*)p; return make_uint2(v.x, v.y); }
+PT_DEV uint4 gload_u4(const void* p) { pt_u4n v = *(const PT_GLOBAL pt_u4n*)p; return make_uint4(v.x, v.y, v.z, v.w); }
 
 // x / C for an integer-valued x in [0, 65535] and C = 255, 1023 or 65535 (unorm decoding): three instructions that give the
 // correctly rounded quotient -- bit for bit what the IEEE division gives, which costs ten.  q = x * RN(1/C) is within an ulp,

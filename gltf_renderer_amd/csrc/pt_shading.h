@@ -144,6 +144,9 @@ PT_DEV RTex load_rtex(const RTex* p) {                      // 3 x dwordx4, issu
 #ifndef PT_TEX_PAIRS
 #define PT_TEX_PAIRS 1      // the two texels of a row in ONE 8-byte load (0: four dword gathers per fetch)
 #endif
+#ifndef PT_TEX_TRIO
+#define PT_TEX_TRIO 1       // materials flagged RM_TRIO fetch albedo + normal + metal-rough from the interleaved copy (0: never; needs PT_TEX_PAIRS)
+#endif
 #if PT_TEX_PAIRS
 // Both texels of a row come from one 8-byte load at the pair's base column ia = clamp(i0, 0, width - 2): element i - ia of it.  Only
 // a tap whose second column wrapped or mirrored off the pair (i0 = width - 1 with WRAP) needs its own loads, and the whole wave
@@ -151,6 +154,10 @@ PT_DEV RTex load_rtex(const RTex* p) {                      // 3 x dwordx4, issu
 struct TexTaps { const uint32_t *p0, *p1; int i0, i1, ia, width; float w00, w10, w01, w11; uint32_t srgb; bool edge; };
 struct TexQuad { uint32_t t00, t10, t01, t11; };
 PT_DEV TexTaps texture_taps(const RTex& t, const vec2 tc[2]) {
+    // No fused multiply-add in here: the compiler contracts each inlined copy of this function on its own, and two textures with the
+    // same transform and size must get the same texels and weights to the bit (a material's interleaved footprint is fetched with the
+    // albedo texture's taps).  Plain products and sums are also what the CPU oracle computes.
+#pragma clang fp contract(off)
     const vec2 uv = (t.flags & RT_TEXCOORD1) ? tc[1] : tc[0];
     const float tu = t.m00 * uv.x + t.m01 * uv.y + t.ox;
     const float tv = t.m10 * uv.x + t.m11 * uv.y + t.oy;
@@ -196,6 +203,10 @@ PT_DEV vec4 resolve_taps(const TexTaps& k, const TexQuad& q, const float* srgb_l
 #else
 struct TexTaps { const uint32_t *p00, *p10, *p01, *p11; float w00, w10, w01, w11; uint32_t srgb; };
 PT_DEV TexTaps texture_taps(const RTex& t, const vec2 tc[2]) {
+    // No fused multiply-add in here: the compiler contracts each inlined copy of this function on its own, and two textures with the
+    // same transform and size must get the same texels and weights to the bit (a material's interleaved footprint is fetched with the
+    // albedo texture's taps).  Plain products and sums are also what the CPU oracle computes.
+#pragma clang fp contract(off)
     const vec2 uv = (t.flags & RT_TEXCOORD1) ? tc[1] : tc[0];
     const float tu = t.m00 * uv.x + t.m01 * uv.y + t.ox;
     const float tv = t.m10 * uv.x + t.m11 * uv.y + t.oy;
@@ -387,6 +398,7 @@ struct MatHeader {                     // the 128-B head of RMat in registers (8
     float clearcoat_roughness_factor, anisotropy_strength, anisotropy_cos, anisotropy_sin;
     vec3 sheen_color_factor; float sheen_roughness_factor;
     float transmission_factor; uint32_t bound_mask;
+    const uint4* trio;                 // valid when bound_mask & RM_TRIO
 };
 PT_DEV MatHeader load_mat_header(const RMat* m) {
     const float4* q = (const float4*)m;
@@ -400,6 +412,7 @@ PT_DEV MatHeader load_mat_header(const RMat* m) {
     r.clearcoat_roughness_factor = f.x; r.anisotropy_strength = f.y; r.anisotropy_cos = f.z; r.anisotropy_sin = f.w;
     r.sheen_color_factor = v3(g.x, g.y, g.z); r.sheen_roughness_factor = g.w;
     r.transmission_factor = h.x; r.bound_mask = __float_as_uint(h.y);
+    r.trio = (const uint4*)(((uint64_t)__float_as_uint(h.w) << 32) | (uint64_t)__float_as_uint(h.z));
     return r;
 }
 PT_DEV bool slot_bound(uint32_t mask, int slot) { return (mask >> slot) & 1u; }
@@ -465,6 +478,43 @@ PT_DEV Surface get_surface(const SceneRec& sc, uint32_t flags, const RMat* m, co
     // The three usual PBR textures are fetched as ONE batch: their slot records are loaded together, their twelve texel
     // gathers are issued together (unbound slots read a 1x1 white texel, so there is no branch to split the batch).
     const uint32_t mid = (uint32_t)(m - sc.rmats);
+#if PT_TEX_PAIRS && PT_TEX_TRIO
+    // Materials whose three textures share one footprint (RM_TRIO, the usual glTF PBR set) read it from the interleaved copy: one set
+    // of addresses and weights, two dwordx4 per texel row.  Both paths are wave-uniform branches; a wave of trio materials only (every
+    // wave of the bench scene) never enters the general one.
+    const bool trio = (h.bound_mask & RM_TRIO) != 0;
+    const RTex t_alb = material_slot012(sc, mid, SLOT_ALBEDO);
+    const TexTaps k_alb = texture_taps(t_alb, a.tc);
+    TexTaps k_nrm = k_alb, k_mr = k_alb;
+    k_nrm.srgb = (h.bound_mask & RM_TRIO_SRGB_N) ? (uint32_t)RT_SRGB : 0u; k_mr.srgb = (h.bound_mask & RM_TRIO_SRGB_M) ? (uint32_t)RT_SRGB : 0u;
+    uint32_t a00 = 0, a10 = 0, a01 = 0, a11 = 0, n00 = 0, n10 = 0, n01 = 0, n11 = 0, m00 = 0, m10 = 0, m01 = 0, m11 = 0;
+    if (__any(trio)) {
+        if (trio) {
+            const uint4* row0 = h.trio + (k_alb.p0 - t_alb.texels) + k_alb.ia;
+            const uint4* row1 = h.trio + (k_alb.p1 - t_alb.texels) + k_alb.ia;
+            const uint4 A0 = gload_u4(row0), B0 = gload_u4(row0 + 1), A1 = gload_u4(row1), B1 = gload_u4(row1 + 1);
+            uint4 t00 = k_alb.i0 == k_alb.ia ? A0 : B0, t01 = k_alb.i0 == k_alb.ia ? A1 : B1;
+            uint4 t10 = k_alb.i1 == k_alb.ia ? A0 : B0, t11 = k_alb.i1 == k_alb.ia ? A1 : B1;
+            if (__any(k_alb.edge)) {
+                if (k_alb.edge) { t10 = gload_u4(h.trio + (k_alb.p0 - t_alb.texels) + k_alb.i1); t11 = gload_u4(h.trio + (k_alb.p1 - t_alb.texels) + k_alb.i1); }
+            }
+            a00 = t00.x; a10 = t10.x; a01 = t01.x; a11 = t11.x;
+            n00 = t00.y; n10 = t10.y; n01 = t01.y; n11 = t11.y;
+            m00 = t00.z; m10 = t10.z; m01 = t01.z; m11 = t11.z;
+        }
+    }
+    if (__any(!trio)) {
+        if (!trio) {
+            const RTex t_nrm = material_slot012(sc, mid, SLOT_NORMAL), t_mr = material_slot012(sc, mid, SLOT_METALLIC_ROUGHNESS);
+            k_nrm = texture_taps(t_nrm, a.tc); k_mr = texture_taps(t_mr, a.tc);
+            const uint2 ar0 = tap_row(k_alb, 0), ar1 = tap_row(k_alb, 1), nr0 = tap_row(k_nrm, 0), nr1 = tap_row(k_nrm, 1), mr0 = tap_row(k_mr, 0), mr1 = tap_row(k_mr, 1);
+            const TexQuad qa = tap_quad(k_alb, ar0, ar1), qn = tap_quad(k_nrm, nr0, nr1), qm = tap_quad(k_mr, mr0, mr1);
+            a00 = qa.t00; a10 = qa.t10; a01 = qa.t01; a11 = qa.t11;
+            n00 = qn.t00; n10 = qn.t10; n01 = qn.t01; n11 = qn.t11;
+            m00 = qm.t00; m10 = qm.t10; m01 = qm.t01; m11 = qm.t11;
+        }
+    }
+#else
     const RTex t_alb = material_slot012(sc, mid, SLOT_ALBEDO), t_nrm = material_slot012(sc, mid, SLOT_NORMAL), t_mr = material_slot012(sc, mid, SLOT_METALLIC_ROUGHNESS);
     const TexTaps k_alb = texture_taps(t_alb, a.tc), k_nrm = texture_taps(t_nrm, a.tc), k_mr = texture_taps(t_mr, a.tc);
 #if PT_TEX_PAIRS
@@ -477,6 +527,7 @@ PT_DEV Surface get_surface(const SceneRec& sc, uint32_t flags, const RMat* m, co
     const uint32_t a00 = gload(k_alb.p00), a10 = gload(k_alb.p10), a01 = gload(k_alb.p01), a11 = gload(k_alb.p11);
     const uint32_t n00 = gload(k_nrm.p00), n10 = gload(k_nrm.p10), n01 = gload(k_nrm.p01), n11 = gload(k_nrm.p11);
     const uint32_t m00 = gload(k_mr.p00), m10 = gload(k_mr.p10), m01 = gload(k_mr.p01), m11 = gload(k_mr.p11);
+#endif
 #endif
     const bool b_alb = slot_bound(h.bound_mask, SLOT_ALBEDO), b_nrm = slot_bound(h.bound_mask, SLOT_NORMAL), b_mr = slot_bound(h.bound_mask, SLOT_METALLIC_ROUGHNESS);
     taps += (b_alb ? 1u : 0u) + (b_nrm ? 1u : 0u) + (b_mr ? 1u : 0u);
@@ -506,7 +557,7 @@ PT_DEV Surface get_surface(const SceneRec& sc, uint32_t flags, const RMat* m, co
     float sheen_rough = h.sheen_roughness_factor;                                                 // :219-226
     s.transmissive = h.transmission_factor;                                                       // :228-235
 #ifndef PT_PROBE_BASE_ONLY
-    if (h.bound_mask >> SLOT_SPECULAR) {                   // any of the rarely-bound extension textures (slots 5..14)
+    if ((h.bound_mask & ((1u << SLOT_COUNT) - 1u)) >> SLOT_SPECULAR) {   // any of the rarely-bound extension textures (slots 5..14)
         if (slot_bound(h.bound_mask, SLOT_SPECULAR)) s.spec_factor *= sample_slot(sc, m, SLOT_SPECULAR, a.tc, taps).w;
         if (slot_bound(h.bound_mask, SLOT_SPECULAR_COLOR)) s.spec_color = s.spec_color * xyz(sample_slot(sc, m, SLOT_SPECULAR_COLOR, a.tc, taps));
         if (slot_bound(h.bound_mask, SLOT_CLEARCOAT)) s.clearcoat *= sample_slot(sc, m, SLOT_CLEARCOAT, a.tc, taps).x;

@@ -57,6 +57,11 @@ struct __attribute__((aligned(16))) RTex {
 };
 static_assert(sizeof(RTex) == 48, "RTex");
 enum { RT_SRGB = 1, RT_POINT = 32, RT_TEXCOORD1 = 64 };
+// bound_mask bits beyond the 15 slots.  RM_TRIO: the albedo slot is bound and the bound ones of the normal and metal-rough slots share
+// its image size, sampler state, UV set and UV transform, so the three bilinear footprints are the SAME four texels and `trio` holds
+// them side by side: {albedo, normal, metal-rough, -} per texel.  One footprint then costs two 32-B pieces instead of six 8-B pieces in
+// six different cache lines (a hit's texel fetches were 6 of its ~13 HBM lines).  RM_TRIO_SRGB_N / _M: sRGB flag of the other two.
+enum : uint32_t { RM_TRIO = 1u << 16, RM_TRIO_SRGB_N = 1u << 17, RM_TRIO_SRGB_M = 1u << 18 };
 enum { SLOT_NORMAL = 0, SLOT_ALBEDO, SLOT_METALLIC_ROUGHNESS, SLOT_OCCLUSION, SLOT_EMISSIVE, SLOT_SPECULAR, SLOT_SPECULAR_COLOR, SLOT_CLEARCOAT,
        SLOT_CLEARCOAT_ROUGHNESS, SLOT_CLEARCOAT_NORMAL, SLOT_ANISOTROPY, SLOT_SHEEN_COLOR, SLOT_SHEEN_ROUGHNESS, SLOT_TRANSMISSION, SLOT_THICKNESS,
        SLOT_COUNT };
@@ -68,7 +73,8 @@ struct __attribute__((aligned(16))) RMat {
     float specular_color_factor[3], clearcoat_factor;
     float clearcoat_roughness_factor, anisotropy_strength, anisotropy_cos, anisotropy_sin;   // cos/sin(anisotropy_rotation), fp32
     float sheen_color_factor[3], sheen_roughness_factor;
-    float transmission_factor; uint32_t bound_mask; uint32_t _pad[2];                        // bit k: slot k has a texture
+    float transmission_factor; uint32_t bound_mask;                                          // bit k: slot k has a texture; RM_TRIO* bits below
+    const uint4* trio;              // RM_TRIO: albedo / normal / metal-rough texels interleaved, 16 B a texel (pt_scene_set_materials)
     RTex tex[SLOT_COUNT];
 };
 static_assert(sizeof(RMat) == 128 + 48 * 15, "RMat");

@@ -639,3 +639,114 @@ def test_orthographic_camera_matches_the_oracle(R, oracle_lib):
     e = rel_l2(p.r.tonemap(og), po.tonemap(b))
     assert e <= 1e-3, e
     p.close()
+
+
+def interleave_scene(size=160):
+    """A wall of quads whose materials exercise the interleaved albedo / normal / metal-rough footprint (pt_types.h RM_TRIO) and
+    every reason to stay on the general path: all three textures alike; two of the three; a tiling WRAP transform (footprints that
+    cross the texture's last column); MIRROR / CLAMP and point samplers; a 1-texel-wide texture; and normal maps of another size,
+    another sampler, another UV transform, the second UV set -- side by side, so waves mix both paths."""
+    import math
+    rng = np.random.default_rng(11)
+    s = scenes.SceneData("interleave_cases")
+    TS = abi.PtTextureSample
+    def tex_set(n, w=None):
+        w = w or n
+        h = scenes.value_noise(rng, n, 4, 2)[:, :w] if w != n else scenes.value_noise(rng, n, 4, 2)
+        g = scenes.value_noise(rng, n, 3, 3)[:, :w] if w != n else scenes.value_noise(rng, n, 3, 3)
+        b = s.add_texture(scenes.rgba(0.2 + 0.8 * h, 0.3 + 0.6 * g, 0.9 - 0.7 * h, 0.5 + 0.5 * g), True)
+        mr = s.add_texture(scenes.rgba(np.ones_like(h), 0.2 + 0.7 * g, 0.8 * h), False)
+        nm_full = scenes.normal_map_from_height(scenes.value_noise(rng, n, 4, 2), 3.0)
+        nm = s.add_texture(nm_full[:, :w] if w != n else nm_full, False)
+        return b, mr, nm
+    b64, mr64, nm64 = tex_set(64)
+    b32, mr32, nm32 = tex_set(32)
+    b1, mr1, nm1 = tex_set(16, 1)                       # 1 texel wide, 16 high
+    smp_mc = s.add_sampler(abi.ADDRESS_MIRROR, abi.ADDRESS_CLAMP, abi.FILTER_LINEAR, abi.FILTER_LINEAR)
+    smp_pt = s.add_sampler(abi.ADDRESS_WRAP, abi.ADDRESS_WRAP, abi.FILTER_POINT, abi.FILTER_POINT)
+    tile = dict(rotation=0.4, offset=(0.13, 0.27), scale=(3.0, 2.0))
+    M = scenes.material
+    mats = [
+        M(albedo=TS(b64), metallic_roughness=TS(mr64), normal=TS(nm64)),                                             # interleaved: all three
+        M(albedo=TS(b64), normal=TS(nm64), roughness_factor=0.4),                                                    # interleaved: albedo + normal
+        M(albedo=TS(b32), metallic_roughness=TS(mr32), metalness_factor=1.0),                                        # interleaved: albedo + metal-rough
+        M(albedo=TS(b64, 0, 0, **tile), metallic_roughness=TS(mr64, 0, 0, **tile), normal=TS(nm64, 0, 0, **tile)),   # interleaved, tiled + rotated
+        M(albedo=TS(b32, smp_mc), metallic_roughness=TS(mr32, smp_mc), normal=TS(nm32, smp_mc, 0, 0.0, (0, 0), (2.5, 2.5))),   # general: transform differs
+        M(albedo=TS(b32, smp_mc, 0, 0.0, (0.3, 0.1), (2.5, 2.5)), metallic_roughness=TS(mr32, smp_mc, 0, 0.0, (0.3, 0.1), (2.5, 2.5)),
+          normal=TS(nm32, smp_mc, 0, 0.0, (0.3, 0.1), (2.5, 2.5))),                                                  # interleaved, MIRROR / CLAMP
+        M(albedo=TS(b64, smp_pt, 0, 0.0, (0, 0), (2, 2)), metallic_roughness=TS(mr64, smp_pt, 0, 0.0, (0, 0), (2, 2)), normal=TS(nm64, smp_pt, 0, 0.0, (0, 0), (2, 2))),   # interleaved, point
+        M(albedo=TS(b1, 0, 0, 0.0, (0, 0), (4, 4)), metallic_roughness=TS(mr1, 0, 0, 0.0, (0, 0), (4, 4)), normal=TS(nm1, 0, 0, 0.0, (0, 0), (4, 4))),   # interleaved, width 1
+        M(albedo=TS(b64), metallic_roughness=TS(mr64), normal=TS(nm32)),                                             # general: size differs
+        M(albedo=TS(b64), metallic_roughness=TS(mr64), normal=TS(nm64, smp_mc)),                                     # general: sampler differs
+        M(albedo=TS(b64), metallic_roughness=TS(mr64), normal=TS(nm64, 0, 1)),                                       # general: UV set differs
+        M(normal=TS(nm64), metallic_roughness=TS(mr64)),                                                             # general: no albedo texture
+        M(albedo=TS(b64)),                                                                                           # general: albedo only
+    ]
+    ids = [s.add_material(m) for m in mats]
+    cols = 5
+    for k, mid in enumerate(ids):
+        cx, cz = (k % cols - (cols - 1) / 2) * 1.05, (k // cols - 1) * 1.05
+        g = meshgen.grid(6, 6, (cx - 0.5, 0.0, cz - 0.5), (1, 0, 0), (0, 0, 1), (1, 1))
+        g.uv1 = (g.uv0 * f32(1.7) + f32(0.2)).astype(f32)
+        s.add_mesh(g, None, mid)
+    s.add_light(abi.LIGHT_POINT, position=(0.5, -2.0, 0.3), color=(1, 0.9, 0.8), intensity=30.0)
+    s.add_light(abi.LIGHT_DIRECTIONAL, direction=(0.2, 1.0, -0.3), color=(1, 1, 1), intensity=2.0)
+    s.world_to_view = camera.orbit_world_to_view((0, 0, 0), 3.2, 0.0, 0.0)
+    s.width, s.height = size, size * 3 // 4
+    s.settings.max_bounces = 3
+    s.settings.flags &= ~abi.FLAG_ENVIRONMENT_MAP
+    return s, 7
+
+
+@pytest.mark.parametrize("mode", ["wavefront", "megakernel"])
+def test_interleaved_texel_footprint_is_bit_identical_to_the_general_path(R, oracle_lib, mode, monkeypatch):
+    """pt_scene_set_materials interleaves the albedo / normal / metal-rough texels of the materials whose three footprints coincide;
+    the shade stage then reads two 32-B pieces a row pair instead of six 8-B pieces.  Same texels, same weights: the image must not
+    change by one bit, whatever mix of materials a wave holds, and must match the oracle (which knows nothing of it)."""
+    s, expect_interleaved = interleave_scene()
+    frames = 6
+    def render(env):
+        if env is None: monkeypatch.delenv("MIPT_TEXTURE_INTERLEAVE", raising=False)
+        else: monkeypatch.setenv("MIPT_TEXTURE_INTERLEAVE", env)
+        r = R()
+        if mode == "megakernel": r.set_kernel_mode(1)
+        h = s.upload(r)
+        n = r.L.pt_debug_interleaved_materials(r.h)
+        out = r.create_output(s.width, s.height)
+        for f in range(frames):
+            r.trace(s.settings, s.execute_params(frame=f), out)
+        img = r.readback(out)
+        r.close()
+        return img, n
+    a, na = render(None)
+    b, nb = render("0")
+    assert na == expect_interleaved and nb == 0, (na, nb)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "interleaved footprint changed %d pixels" % int((a != b).any(axis=2).sum())
+    o = oracle_lib.Oracle()
+    s.upload(o)
+    ref = np.zeros((s.height, s.width, 4), np.float32)
+    for f in range(frames):
+        o.trace(s.settings, s.execute_params(frame=f), ref)
+    err = rel_l2(oracle_lib.tonemap(a), oracle_lib.tonemap(ref))
+    assert err <= 1e-3, err
+
+
+def test_interleaved_copies_follow_the_material_table(R):
+    """A new material table releases the copies it no longer names and reuses the ones it does; textures stay destroyable."""
+    s, n = interleave_scene(64)
+    r = R()
+    h = s.upload(r)
+    assert r.L.pt_debug_interleaved_materials(r.h) == n
+    out = r.create_output(s.width, s.height)
+    r.trace(s.settings, s.execute_params(frame=0), out)
+    first = r.readback(out).copy()
+    r.set_materials([abi.PtMaterial.default() for _ in s.materials])          # no texture named any more: every copy goes
+    assert r.L.pt_debug_interleaved_materials(r.h) == 0
+    r.trace(s.settings, s.execute_params(frame=0), out)
+    r.close()
+    r = R()
+    s.upload(r)
+    out = r.create_output(s.width, s.height)
+    r.trace(s.settings, s.execute_params(frame=0), out)
+    assert np.array_equal(first.view(np.uint32), r.readback(out).view(np.uint32))
+    r.close()
