@@ -1001,13 +1001,19 @@ PT_DEV void stage_importance_top(const SceneRec& sc) {   // 256-thread workgroup
     if (sc.has_env) for (uint32_t i = threadIdx.x; i < kImpLdsFloat4; i += 256u) pt_lds_imp[i] = gload_f4((const float4*)sc.env.blocked + i);
     __syncthreads();
 }
-PT_DEV const float4* importance_lds_block(uint32_t float_offset, size_t block) { return pt_lds_imp + float_offset / 4u + block * 4u; }
+PT_DEV const float4* importance_lds_top() { return pt_lds_imp; }
+// the same staging into LDS a caller owns (kImpLdsFloat4 float4; the traversal stages lend their stack memory to the pre-pass)
+PT_DEV void stage_importance_top_into(const SceneRec& sc, float4* dst) {
+    if (sc.has_env) for (uint32_t i = threadIdx.x; i < kImpLdsFloat4; i += 256u) dst[i] = gload_f4((const float4*)sc.env.blocked + i);
+    __syncthreads();
+}
 #else
 constexpr int kImpLdsLevels = 0;
 PT_DEV void stage_importance_top(const SceneRec&) {}
-PT_DEV const float4* importance_lds_block(uint32_t, size_t) { return nullptr; }
+PT_DEV const float4* importance_lds_top() { return nullptr; }
 #endif
-PT_DEV vec2 sample_importance_map(const EnvRec& e, float ux, float uy, float& pdf) {                         // Sampling.hlsli:123-163
+// `lds_top`: the three coarsest level pairs in LDS (importance_lds_top() or a caller's staging), unused when kImpLdsLevels == 0
+PT_DEV vec2 sample_importance_map(const EnvRec& e, float ux, float uy, float& pdf, const float4* lds_top) {    // Sampling.hlsli:123-163
     // The reference descends ten levels with four dependent point loads each.  Here one 64-B fetch of a 4x4 block of the
     // finer level of a pair serves two levels: the coarser level's 2x2 values are re-summed from the block in the order the
     // pyramid build uses (k_importance_level: ((ul + ll) + ur) + lr), which reproduces the stored sums bit for bit.
@@ -1022,7 +1028,7 @@ PT_DEV vec2 sample_importance_map(const EnvRec& e, float ux, float uy, float& pd
         const uint32_t nb = 1u << (2 * k);                                 // blocks per row of this pair's finer level
         const size_t block = (size_t)py * nb + px;
         float4 r0, r1, r2, r3;
-        if (k < kImpLdsLevels) { const float4* blk = importance_lds_block(e.blocked_offset[k], block); r0 = blk[0]; r1 = blk[1]; r2 = blk[2]; r3 = blk[3]; }
+        if (k < kImpLdsLevels) { const float4* blk = lds_top + e.blocked_offset[k] / 4u + block * 4u; r0 = blk[0]; r1 = blk[1]; r2 = blk[2]; r3 = blk[3]; }
         else { const float4* blk = (const float4*)(e.blocked + e.blocked_offset[k]) + block * 4; r0 = blk[0]; r1 = blk[1]; r2 = blk[2]; r3 = blk[3]; }
         const float a_ul = ((r0.x + r1.x) + r0.y) + r1.y, a_ur = ((r0.z + r1.z) + r0.w) + r1.w;
         const float a_ll = ((r2.x + r3.x) + r2.y) + r3.y, a_lr = ((r2.z + r3.z) + r2.w) + r3.w;
@@ -1038,6 +1044,21 @@ PT_DEV vec2 sample_importance_map(const EnvRec& e, float ux, float uy, float& pd
     float w = (float)e.imp_res;
     pdf = w * w * value / e.imp_total;                          // value = level-0 texel (px, py); imp_total = mips[10][0]
     return {((float)px + ux) / w, ((float)py + uy) / w};      // both axes / width (quirk q10)
+}
+// SampleEnvironmentMap's hit-independent half (PathTracer.lib.hlsl:688-703): direction, solid-angle pdf and radiance of the sample
+// the random numbers (u0, u1) pick.  It depends on the pixel's random sequence only, never on the hit, which is what lets the
+// wavefront pipeline draw it ahead of the shade stage (pt_wavefront.hip env_prepass).
+struct EnvSample { vec3 dir; float pdf; vec3 color; };
+PT_DEV EnvSample environment_light_sample(const SceneRec& sc, float environment_intensity, float u0, float u1, const float4* lds_top) {
+    EnvSample e;
+    e.pdf = 1; e.dir = v3(0, 0, 1); e.color = v3(0);
+    if (sc.has_env) {
+        vec2 uv = sample_importance_map(sc.env, u0, u1, e.pdf, lds_top);
+        e.dir = square_to_sphere(uv_to_square(uv));
+        e.pdf /= 4 * kPi;
+        e.color = environment_intensity * sample_cube(sc.env.cube, sc.env.cube_n, e.dir);
+    }
+    return e;
 }
 PT_DEV float importance_map_pdf(const EnvRec& e, vec2 uv) {                                                   // Sampling.hlsli:165-174, Common.hlsli:12-15
     float total = e.imp_total;

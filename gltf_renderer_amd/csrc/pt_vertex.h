@@ -44,22 +44,25 @@ PT_DEV vec3 shade_miss(const SceneRec& sc, const FrameConstants& fc, vec3 dir, c
 // Returns true when the path ends at this vertex for a debug output (fu.add holds beta * debug colour).
 // -DPT_TIMING (pt_wavefront.hip only; tools/shade_sections.py): cycles per section of this function, summed per wave.
 #ifdef PT_TIMING
-extern __device__ unsigned long long pt_timing[8];
+extern __device__ unsigned long long pt_timing[12];
 #define PT_TICK(K) { const unsigned long long _now = __builtin_readcyclecounter(); _sec[K] += _now - _t; _t = _now; }
-#define PT_TICK_FLUSH() { if (__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) { for (int _k = 0; _k < 7; _k++) atomicAdd(&pt_timing[_k], _sec[_k]); atomicAdd(&pt_timing[7], 1ull); } }
+#define PT_TICK_FLUSH() { if (__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) { for (int _k = 0; _k < 11; _k++) atomicAdd(&pt_timing[_k], _sec[_k]); atomicAdd(&pt_timing[11], 1ull); } }
 #else
 #define PT_TICK(K)
 #define PT_TICK_FLUSH()
 #endif
 // `packet`: the hit triangle's shading packet (load_shade_packet_raw(sc.shade + hit.tri)), fetched by the caller so that it can be
 // in flight together with the caller's own fetches.
+// PRE: `pre` is the vertex's environment light sample, drawn ahead of time with this vertex's random numbers (wavefront pipeline:
+// the in-place code, its LDS tables and its registers are not compiled in); otherwise it is drawn here.
+template <bool PRE = false>
 PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint32_t seed, uint32_t px, uint32_t py, const Ray& ray, const HitRec& hit,
-                              const RawPacket& packet, PathState& ps, Followups& fu, unsigned& taps) {
+                              const RawPacket& packet, PathState& ps, Followups& fu, unsigned& taps, const EnvSample* pre = nullptr) {
     const uint32_t flags = fc.flags;
     fu.add = v3(0); fu.overwrite = false; fu.counted_shadow = 0;
     fu.q_env = fu.q_light = fu.q_bounce = false;
 #ifdef PT_TIMING
-    unsigned long long _sec[7] = {0, 0, 0, 0, 0, 0, 0}, _t = __builtin_readcyclecounter();
+    unsigned long long _sec[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, _t = __builtin_readcyclecounter();
 #endif
     const PacketVerts pv = unpack_shade_packet(packet);               // one 128-B line: the three vertices and the instance id
     const ShadeInst inst = load_shade_inst(sc, pv.inst);
@@ -119,15 +122,15 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
     PT_TICK(2)
     // environment NEE :929-942 (SampleEnvironmentMap :688-703)
     if (ps.bounce < fc.max_bounces && (flags & PT_FLAG_ENVIRONMENT_MAP) && (flags & PT_FLAG_ENVIRONMENT_MIS)) {
-        vec4 r = next_random(px, py, seed, ps.rc);
-        float light_pdf = 1;
-        vec3 ldir = v3(0, 0, 1), lcol = v3(0);
-        if (sc.has_env) {
-            vec2 uv = sample_importance_map(sc.env, r.x, r.y, light_pdf);
-            ldir = square_to_sphere(uv_to_square(uv));
-            light_pdf /= 4 * kPi;
-            lcol = fc.environment_intensity * sample_cube(sc.env.cube, sc.env.cube_n, ldir);
+        EnvSample es;
+        if (PRE) { es = *pre; ps.rc++; }                                    // the draw still counts
+        else {
+            vec4 r = next_random(px, py, seed, ps.rc);
+            es = environment_light_sample(sc, fc.environment_intensity, r.x, r.y, importance_lds_top());
         }
+        const float light_pdf = es.pdf;
+        const vec3 ldir = es.dir, lcol = es.color;
+        PT_TICK(6)                                                          // [6] the environment light sample (random numbers, descent, cube)
         vec3 contrib = v3(0);
         if (any_gt0(lcol)) {
             float bp = 0;

@@ -22,11 +22,11 @@
 #include "pt_host.h"
 
 #ifdef PT_TIMING                 // diagnostic build only (tools/shade_sections.py); not part of the C-ABI
-namespace pt { __device__ unsigned long long pt_timing[8]; }
-extern "C" int pt_debug_read_timing(unsigned long long* out8, int reset) {
+namespace pt { __device__ unsigned long long pt_timing[12]; }
+extern "C" int pt_debug_read_timing(unsigned long long* out12, int reset) {
     hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out8, HIP_SYMBOL(pt::pt_timing), 64);
-    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(pt::pt_timing), z, 64); }
+    hipMemcpyFromSymbol(out12, HIP_SYMBOL(pt::pt_timing), 96);
+    if (reset) { unsigned long long z[12] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(pt::pt_timing), z, 96); }
     return 0;
 }
 #endif
@@ -61,6 +61,8 @@ struct WfBuffers {
     float4* ray_o[2];
     float4* ray_d[2];
     float4* hit;          // per entry of the current queue: t, u, v, bits: tri | front << 31 (kMissTri: miss)
+    float4* env_a;        // per entry of the current closest queue: the vertex's environment light sample, drawn by the traversal stage that
+    float4* env_b;        // traces the entry (env_prepass): (direction, pdf), (radiance, -)
     // shadow queue, kShards segments of 2 * seg_cap entries: (o.xyz, bits: slot | is_light << 31), (d.xyz, tmax)
     float4* sh_o;
     float4* sh_d;
@@ -304,6 +306,44 @@ PT_DEV void trace_persistent(const SceneRec& sc, const WfBuffers& wf, int* my_st
 #endif
 }
 
+// Environment light samples of the path vertices the closest-hit rays of queue `cur` will reach (SampleEnvironmentMap,
+// PathTracer.lib.hlsl:688-703: random numbers -> importance-map descent -> direction -> cube-map radiance).  The sample depends on the
+// pixel's random sequence only, not on the hit, so it is drawn HERE, by the small-register traversal kernel at 6 waves per SIMD,
+// where its three dependent gathers hide behind other waves, instead of in the shade stage at 2 waves per SIMD, where they were a
+// fifth of that stage's time (tools/shade_sections.py).  The shade stage reads the result with the queue entry (coalesced, no extra
+// round trip) and still counts the draw.  LDS: the importance pyramid's coarse levels are staged into the traversal stack's memory,
+// which is idle until the traversal starts.
+// Every traversal workgroup draws its share of the shard's samples before it starts traversing.  Measured per 8-spp launch of the bench
+// scene: the shade stage 12.1 -> 10.5 ms, the traversal stages 13.0 -> 14.4 ms -- the ~2 k vector instructions of a sample cost nearly as
+// much here as there (+0.8 % overall, and 17 KB of LDS a shade workgroup no longer needs).  Handing the samples to dedicated workgroups
+// prepended to the traversal launch (1-3 per shard), so that their arithmetic would fill the issue slots of the memory-bound traversal
+// waves beside them, was slower still (traversal 14.9-15.0 ms): those slots are not idle.
+#ifndef PT_ENV_PREPASS
+#define PT_ENV_PREPASS 1
+#endif
+
+PT_DEV bool env_prepass_wanted(const SceneRec& sc, const FrameConstants& fc, int vertex_bounce) {
+    return PT_ENV_PREPASS && sc.has_env && (fc.flags & PT_FLAG_ENVIRONMENT_MAP) && (fc.flags & PT_FLAG_ENVIRONMENT_MIS) && vertex_bounce < fc.max_bounces;
+}
+PT_DEV void env_prepass(const SceneRec& sc, const FrameConstants& fc, const WfBuffers& wf, int* stack_lds, const ShardView& sv, int cur) {
+    static_assert((size_t)kStackLds * kBlock * sizeof(int) >= (size_t)kImpLdsFloat4 * sizeof(float4), "the traversal stack's LDS must hold the importance pyramid's coarse levels");
+    float4* top = (float4*)stack_lds;
+    stage_importance_top_into(sc, top);
+    const uint32_t n = wf.cnt[cur][sv.shard * kCounterStride];
+    const size_t base = (size_t)sv.shard * wf.seg_cap;
+    for (uint32_t i = sv.member * kBlock + threadIdx.x; i < n; i += sv.stride) {
+        const uint32_t slot = QLD(*((const uint32_t*)&wf.ray_d[cur][base + i] + 3));
+        int rc = (int)(SLD(*((const uint32_t*)&wf.thr_misc[SIDX(slot)] + 3)) & 0xffffu);
+        uint32_t px, py;
+        slot_pixel(fc, slot, px, py);
+        const vec4 r = next_random(px, py, sample_seed(fc, slot_sample(fc, slot)), rc);
+        const EnvSample e = environment_light_sample(sc, fc.environment_intensity, r.x, r.y, top);
+        QST(wf.env_a[base + i], make_float4(e.dir.x, e.dir.y, e.dir.z, e.pdf));
+        QST(wf.env_b[base + i], make_float4(e.color.x, e.color.y, e.color.z, 0.0f));
+    }
+    __syncthreads();                       // the stack memory goes back to the traversal
+}
+
 #ifndef PT_TRACE_WAVES
 #define PT_TRACE_WAVES 1
 #endif
@@ -315,10 +355,11 @@ PT_DEV void trace_persistent(const SceneRec& sc, const WfBuffers& wf, int* my_st
 #endif
 // `bounce` = the bounce whose shade stage follows: it fills closest queue cur ^ 1 and the shadow counter of that bounce.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_trace(SceneRec sc, WfBuffers wf, int cur, int bounce, uint32_t rf, uint32_t rmask, Counters* __restrict__ counters) {
+__global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_trace(SceneRec sc, FrameConstants fc, WfBuffers wf, int cur, int bounce, uint32_t rf, uint32_t rmask, Counters* __restrict__ counters) {
     __shared__ int s_stack[kStackLds * kBlock];
     stage_luts(sc);
     const ShardView sv = shard_view(wf);
+    if (env_prepass_wanted(sc, fc, bounce)) env_prepass(sc, fc, wf, s_stack, sv, cur);
     // member 0 of each shard zeroes the counters the following shade stage fills
     if (sv.member == 0 && threadIdx.x == 0) { wf.cnt[cur ^ 1][sv.shard * kCounterStride] = 0; wf.cnt[shadow_counter(bounce)][sv.shard * kCounterStride] = 0; wf.cnt[6][sv.shard * kCounterStride] = 0; }
     LaneStats st = {0, 0, 0, 0};
@@ -333,11 +374,12 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_trace(SceneRec sc
 // grid-wide synchronisations per bounce instead of three (each one ends on its slowest wave: ~0.07 ms of a 5.5-ms 1-spp frame).
 // `nxt` = closest queue the shade stage of `bounce` filled.  Zeroes what the shade stage of bounce + 1 fills.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_traverse(SceneRec sc, WfBuffers wf, int nxt, int bounce, uint32_t rf, uint32_t rmask, uint32_t flags,
+__global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_traverse(SceneRec sc, FrameConstants fc, WfBuffers wf, int nxt, int bounce, uint32_t rf, uint32_t rmask, uint32_t flags,
                                                                         Counters* __restrict__ counters) {
     __shared__ int s_stack[kStackLds * kBlock];
     stage_luts(sc);
     const ShardView sv = shard_view(wf);
+    if (env_prepass_wanted(sc, fc, bounce + 1)) env_prepass(sc, fc, wf, s_stack, sv, nxt);
     if (sv.member == 0 && threadIdx.x == 0) { wf.cnt[nxt ^ 1][sv.shard * kCounterStride] = 0; wf.cnt[shadow_counter(bounce + 1)][sv.shard * kCounterStride] = 0; wf.cnt[6][sv.shard * kCounterStride] = 0; }
     LaneStats st_shadow = {0, 0, 0, 0}, st = {0, 0, 0, 0};
     trace_persistent<COUNT, 1>(sc, wf, s_stack + threadIdx.x, sv, shadow_counter(bounce), 0, 0xff, flags, st_shadow);
@@ -371,7 +413,9 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
     }
     stage_luts(sc);
     stage_tangent_lut(sc);
+#if !PT_ENV_PREPASS
     stage_importance_top(sc);
+#endif
     stage_lights(sc, fc.num_of_lights);
     stage_instances(sc);
     stage_materials(sc);
@@ -414,6 +458,16 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
         ps.beta = v3(0); ps.thr = v3(0); ps.prev_pdf = 0; ps.rc = 0; ps.bounce = 0; ps.prev_mis = false;
         if (active) {
             const float4 o = QLD(wf.ray_o[cur][base + i]), d = QLD(wf.ray_d[cur][base + i]), h = QLD(wf.hit[base + i]);
+#if PT_ENV_PREPASS
+            // the vertex's environment light sample, drawn by the traversal stage (env_prepass); without an environment the sample is
+            // the constant the in-place code produces.  Fetched with the entry whether or not this vertex will use it: no extra round trip.
+            EnvSample es;
+            es.dir = v3(0, 0, 1); es.pdf = 1; es.color = v3(0);
+            if (env_prepass_wanted(sc, fc, bounce)) {
+                const float4 ea = QLD(wf.env_a[base + i]), eb = QLD(wf.env_b[base + i]);
+                es.dir = v3(ea.x, ea.y, ea.z); es.pdf = ea.w; es.color = v3(eb.x, eb.y, eb.z);
+            }
+#endif
             slot = __float_as_uint(d.w);
             Ray ray;
             ray.o = v3(o.x, o.y, o.z); ray.tmin = 0; ray.d = v3(d.x, d.y, d.z); ray.tmax = o.w;
@@ -435,7 +489,11 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
                 uint32_t px, py;
                 slot_pixel(fc, slot, px, py);
                 n_hits++;
+#if PT_ENV_PREPASS
+                const bool done = shade_closest_hit<true>(sc, fc, sample_seed(fc, slot_sample(fc, slot)), px, py, ray, hit, packet, ps, fu, st.taps, &es);
+#else
                 const bool done = shade_closest_hit(sc, fc, sample_seed(fc, slot_sample(fc, slot)), px, py, ray, hit, packet, ps, fu, st.taps);
+#endif
                 if (fu.overwrite) L = v3(0);
                 L += fu.add;
                 n_shadow += fu.counted_shadow;
@@ -541,7 +599,7 @@ size_t wavefront_workspace_bytes(const FrameConstants& fc, int stage_blocks) {
     const uint32_t bps = blocks_per_shard_for(stage_blocks);
     const size_t slots = state_slots_for((size_t)fc.my_tiles * kBlock * fc.spp);
     const size_t q = (size_t)kShards * seg_cap_for(fc, bps);
-    return slots * (5 * 16 + 4) + q * (4 * 16 + 16 + 2 * 2 * 16) + kCounterArrays * kShards * kCounterStride * 4 + 32 * 256;
+    return slots * (5 * 16 + 4) + q * (4 * 16 + 16 + 2 * 16 + 2 * 2 * 16) + kCounterArrays * kShards * kCounterStride * 4 + 32 * 256;
 }
 
 static WfBuffers carve(void* base, const FrameConstants& fc, int stage_blocks) {
@@ -565,6 +623,8 @@ static WfBuffers carve(void* base, const FrameConstants& fc, int stage_blocks) {
     wf.pflags = (uint32_t*)take(state_slots * 4);
     for (int k = 0; k < 2; k++) { wf.ray_o[k] = (float4*)take(q * 16); wf.ray_d[k] = (float4*)take(q * 16); }
     wf.hit = (float4*)take(q * 16);
+    wf.env_a = (float4*)take(q * 16);
+    wf.env_b = (float4*)take(q * 16);
     wf.sh_o = (float4*)take(q * 2 * 16);
     wf.sh_d = (float4*)take(q * 2 * 16);
     wf.capacity = slots;
@@ -645,11 +705,11 @@ hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4
         ray_flags(0, rf, rmask);
 #if PT_LATE_GRID
         const dim3 g0 = cap(stage, env_trace_bps);
-        if (count) hipLaunchKernelGGL(k_wf_trace<true>, g0, block, 0, stream, sc, wf_of(g0), 0, 0, rf, rmask, counters);
-        else hipLaunchKernelGGL(k_wf_trace<false>, g0, block, 0, stream, sc, wf_of(g0), 0, 0, rf, rmask, counters);
+        if (count) hipLaunchKernelGGL(k_wf_trace<true>, g0, block, 0, stream, sc, fc, wf_of(g0), 0, 0, rf, rmask, counters);
+        else hipLaunchKernelGGL(k_wf_trace<false>, g0, block, 0, stream, sc, fc, wf_of(g0), 0, 0, rf, rmask, counters);
 #else
-        if (count) hipLaunchKernelGGL(k_wf_trace<true>, stage, block, 0, stream, sc, wf, 0, 0, rf, rmask, counters);
-        else hipLaunchKernelGGL(k_wf_trace<false>, stage, block, 0, stream, sc, wf, 0, 0, rf, rmask, counters);
+        if (count) hipLaunchKernelGGL(k_wf_trace<true>, stage, block, 0, stream, sc, fc, wf, 0, 0, rf, rmask, counters);
+        else hipLaunchKernelGGL(k_wf_trace<false>, stage, block, 0, stream, sc, fc, wf, 0, 0, rf, rmask, counters);
 #endif
         mark(STAGE_TRACE);
     }
@@ -667,8 +727,8 @@ hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4
         uint32_t rf, rmask;
         ray_flags(b + 1, rf, rmask);
         if (b + 1 < iterations) {
-            if (count) hipLaunchKernelGGL(k_wf_traverse<true>, gt, block, 0, stream, sc, wt, cur ^ 1, b, rf, rmask, flags, counters);
-            else hipLaunchKernelGGL(k_wf_traverse<false>, gt, block, 0, stream, sc, wt, cur ^ 1, b, rf, rmask, flags, counters);
+            if (count) hipLaunchKernelGGL(k_wf_traverse<true>, gt, block, 0, stream, sc, fc, wt, cur ^ 1, b, rf, rmask, flags, counters);
+            else hipLaunchKernelGGL(k_wf_traverse<false>, gt, block, 0, stream, sc, fc, wt, cur ^ 1, b, rf, rmask, flags, counters);
         } else {                                                                                      // the last vertex pushes no bounce ray
             if (count) hipLaunchKernelGGL(k_wf_shadow<true>, gt, block, 0, stream, sc, wt, b, flags, counters);
             else hipLaunchKernelGGL(k_wf_shadow<false>, gt, block, 0, stream, sc, wt, b, flags, counters);
@@ -680,8 +740,8 @@ hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4
         const int cur = b & 1;
         uint32_t rf, rmask;
         ray_flags(b, rf, rmask);
-        if (count) hipLaunchKernelGGL(k_wf_trace<true>, stage, block, 0, stream, sc, wf, cur, b, rf, rmask, counters);
-        else hipLaunchKernelGGL(k_wf_trace<false>, stage, block, 0, stream, sc, wf, cur, b, rf, rmask, counters);
+        if (count) hipLaunchKernelGGL(k_wf_trace<true>, stage, block, 0, stream, sc, fc, wf, cur, b, rf, rmask, counters);
+        else hipLaunchKernelGGL(k_wf_trace<false>, stage, block, 0, stream, sc, fc, wf, cur, b, rf, rmask, counters);
         mark(STAGE_TRACE);
         hipLaunchKernelGGL(k_wf_shade, stage, block, 0, stream, sc, fc, wf, cur, b, counters);
         mark(STAGE_SHADE);
