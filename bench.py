@@ -370,7 +370,13 @@ def main():
         # instance row, the three coarsest level pairs of the importance pyramid) instead of fetching per hit
         lds = c.closest_hits * (640 + 176 + (96 if env_mis else 0)) / n
         ms = {"traversal": stage_ms[1] + stage_ms[3], "shade": stage_ms[2], "generate+resolve": stage_ms[0] + stage_ms[4]}
-        roofs = {"traversal": ("Infinity-Cache gather (MI355X_MICROARCH.md: 8.6 TB/s; L2-resident gather 16.8-18.8 TB/s)", 8600.0), "shade": ("HBM", 8000.0), "generate+resolve": ("HBM", 8000.0)}
+        # roofs: the traversal stages gather 64-B nodes / 48-B triangle packets that live in the L2s and the Infinity Cache, so their roof is
+        # the MEASURED gather ceiling of that very access pattern at their occupancy (tools/probes/quadload_probe.hip, profiles/
+        # r02e_microbenchmarks.txt: 200 G node fetches/s = 12.8 TB/s L2-resident, 65 G/s = 4.2 TB/s Infinity-Cache-resident; the guide's
+        # figures: L2 gather 16.8-18.8 TB/s, Infinity-Cache gather 8.6 TB/s); the shade stage's scattered lines come from HBM.
+        roofs = {"traversal": ("L2-resident 64-B gather, measured with this access pattern at 6 waves/SIMD (tools/probes/quadload_probe.hip: 12.8 TB/s; "
+                               "Infinity-Cache-resident 4.2 TB/s; MI355X_MICROARCH.md: L2 gather 16.8-18.8, Infinity-Cache gather 8.6 TB/s)", 12800.0),
+                 "shade": ("HBM", 8000.0), "generate+resolve": ("HBM", 8000.0)}
         pmc = {}
         pmc_file = os.path.join("profiles", "r02_pmc_per_kernel.json")
         if os.path.exists(os.path.join(ROOT, pmc_file)) and args.config == "sponza" and not (args.width or args.height or args.animate):
@@ -394,8 +400,20 @@ def main():
             if k2 in pmc:
                 e["pmc"] = pmc[k2]
             stages[k2] = e
-        dominant = "shade"      # the single kernel with the largest share of a launch (the traversal figure sums two kernels)
-        kernel_of = {"shade": "k_wf_shade"}
+        # the kernel family with the largest share of a launch: k_wf_shade, or the traversal kernels (k_wf_traverse -- the shadow rays of a
+        # bounce and the closest-hit rays of the next -- with the primary rays' k_wf_trace and the last k_wf_shadow: one code path,
+        # trace_persistent, timed together by the stage events)
+        dominant = "traversal" if ms["traversal"] > ms["shade"] else "shade"
+        kernel_of = {"shade": "k_wf_shade", "traversal": "k_wf_traverse + k_wf_trace + k_wf_shadow (one traversal code path)"}
+        for k2 in ("traversal", "shade"):
+            if "pmc" in stages[k2]:     # what the counters say the stage moved, beside what the algorithm asks for
+                stages[k2]["hbm_traffic_GBps"] = round(stages[k2]["pmc"]["hbm_bytes_per_launch"] / max(ms[k2], 1e-9) / 1e6, 1)
+                stages[k2]["hbm_random_line_ceiling_GBps"] = 6400.0      # tools/probes/random_sector_probe.hip: ~50 G random 128-B lines/s
+        limiter = {"shade": "scattered cache lines from HBM (a gather is priced at its 128-B line: ~50 G random lines/s = 6.4 TB/s is the chip's ceiling, "
+                            "profiles/r02e_microbenchmarks.txt) and ~7 k dependent vector instructions per hit at 2 waves/SIMD (DESIGN.md section 4)",
+                   "traversal": "cache-gather rate, not HBM: nodes and triangle packets are L2 / Infinity-Cache resident (HBM traffic is a fifth of the algorithmic "
+                                "bytes); measured against the gather ceiling of the same access pattern (stages.traversal.roof), with ~160 vector instructions "
+                                "per node step that are not hidden (DESIGN.md section 4)"}
         total_ms = sum(ms.values())
         mean_ms = sum(kernel_ms) / len(kernel_ms)
         total_alg = sum(alg.values())
@@ -406,7 +424,7 @@ def main():
                                       % (kernel_of[dominant], 100.0 * ms[dominant] / max(total_ms, 1e-9), spp, settings.max_bounces + 1),
             "achieved": d["achieved_GBps"], "peak": 8000.0, "unit": "GB/s", "frac": round(d["achieved_GBps"] / 8000.0, 5),
             "traffic": traffic, "traffic_source": (pmc_file + " (rocprofv3 --pmc passes of this command, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, summed over the kernel's launches of one pt_trace)") if traffic else None,
-            "limiter": "not HBM: dependent-gather latency and vector-memory issue (DESIGN.md section 4); the traversal stages read L2 / Infinity-Cache resident data",
+            "limiter": limiter[dominant], "roof_that_applies": d["roof"], "roof_GBps": d["roof_GBps"], "frac_of_applicable_roof": d["frac_of_roof"],
             "stages": stages,
             "pipeline": {"kernel_ms_mean_timed": round(mean_ms, 4), "stage_ms_sum_replay": round(total_ms, 4), "algorithmic_bytes_per_launch": round(total_alg),
                          "achieved_GBps": round(total_alg / (mean_ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(total_alg / (mean_ms * 1e-3) / 1e9 / 8000.0, 4),
