@@ -887,14 +887,30 @@ PT_DEV vec3 sample_bsdf(uint32_t flags, const float* lut, const Surface& s, cons
 #ifdef PT_LUT_LDS
 constexpr int kLightCacheMax = 32;
 static __shared__ float4 pt_lds_light[kLightCacheMax * 4];
+// A spot light's cone terms (Lights.hlsli:52-55: two cosines and a division that depend on the light alone) are evaluated ONCE per
+// staged light, by the expressions light_ray() uses, and kept in the record's two padding floats of the LDS copy: every wave holds a
+// lane that picked the spot light, so every hit used to pay for them.
+PT_DEV void spot_cone_terms(float inner_angle, float outer_angle, float& scale, float& offset) {
+    scale = 1.0f / hmax(0.001f, cosf(inner_angle) - cosf(outer_angle));
+    offset = -cosf(outer_angle) * scale;
+}
 PT_DEV void stage_lights(const SceneRec& sc, int num_of_lights) {   // 256-thread workgroups
-    const uint32_t n4 = (uint32_t)(num_of_lights < kLightCacheMax ? num_of_lights : kLightCacheMax) * 4u;
+    const uint32_t n = (uint32_t)(num_of_lights < kLightCacheMax ? num_of_lights : kLightCacheMax), n4 = n * 4u;
     if (threadIdx.x < n4) pt_lds_light[threadIdx.x] = gload_f4((const float4*)sc.lights + threadIdx.x);
     __syncthreads();
+    if (threadIdx.x < n) {
+        // pt_light as floats: [0] type [1-3] position [4] cutoff [5-7] direction [8] intensity [9-11] color [12] inner [13] outer [14-15] pad
+        float4& last = pt_lds_light[threadIdx.x * 4u + 3u];        // inner_angle, outer_angle, pad, pad
+        float scale, offset;
+        spot_cone_terms(last.x, last.y, scale, offset);
+        last.z = scale; last.w = offset;
+    }
+    __syncthreads();
 }
-PT_DEV pt_light load_light(const SceneRec& sc, uint32_t li) {
+PT_DEV pt_light load_light(const SceneRec& sc, uint32_t li, bool& cone_terms_staged) {
     float4 q[4];
-    if (li < (uint32_t)kLightCacheMax) { const float4* p = pt_lds_light + li * 4u; q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; q[3] = p[3]; }
+    cone_terms_staged = li < (uint32_t)kLightCacheMax;
+    if (cone_terms_staged) { const float4* p = pt_lds_light + li * 4u; q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; q[3] = p[3]; }
     else { const float4* p = (const float4*)sc.lights + (size_t)li * 4u; q[0] = gload_f4(p); q[1] = gload_f4(p + 1); q[2] = gload_f4(p + 2); q[3] = gload_f4(p + 3); }
     pt_light l;
     static_assert(sizeof(pt_light) == 64, "pt_light");
@@ -902,10 +918,15 @@ PT_DEV pt_light load_light(const SceneRec& sc, uint32_t li) {
     return l;
 }
 #else
+PT_DEV void spot_cone_terms(float inner_angle, float outer_angle, float& scale, float& offset) {
+    scale = 1.0f / hmax(0.001f, cosf(inner_angle) - cosf(outer_angle));
+    offset = -cosf(outer_angle) * scale;
+}
 PT_DEV void stage_lights(const SceneRec&, int) {}
-PT_DEV pt_light load_light(const SceneRec& sc, uint32_t li) { return sc.lights[li]; }
+PT_DEV pt_light load_light(const SceneRec& sc, uint32_t li, bool& cone_terms_staged) { cone_terms_staged = false; return sc.lights[li]; }
 #endif
-PT_DEV void light_ray(const pt_light& light, vec3 p, vec3& dir, vec3& color) {
+// cone_terms_staged: the record's padding holds spot_cone_terms() of this light (the LDS copy)
+PT_DEV void light_ray(const pt_light& light, vec3 p, vec3& dir, vec3& color, bool cone_terms_staged = false) {
     bool local = light.type == PT_LIGHT_POINT || light.type == PT_LIGHT_SPOT;
     if (local) dir = v3p(light.position) - p;
     else dir = -v3p(light.direction);
@@ -919,8 +940,9 @@ PT_DEV void light_ray(const pt_light& light, vec3 p, vec3& dir, vec3& color) {
     }
     dir = normalize(dir);
     if (light.type == PT_LIGHT_SPOT) {
-        float scale = 1.0f / hmax(0.001f, cosf(light.inner_angle) - cosf(light.outer_angle));
-        float offset = -cosf(light.outer_angle) * scale;
+        float scale, offset;
+        if (cone_terms_staged) { float staged[2]; memcpy(staged, light.pad, 8); scale = staged[0]; offset = staged[1]; }
+        else spot_cone_terms(light.inner_angle, light.outer_angle, scale, offset);
         float cd = -dot(normalize(v3p(light.direction)), dir);
         float att = saturate(cd * scale + offset);
         att *= att;

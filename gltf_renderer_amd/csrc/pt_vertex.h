@@ -155,8 +155,9 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
         li = min(li, (uint32_t)(fc.num_of_lights - 1));                                              // u may be exactly 1 (quirk q17)
         float pdf = 1.0f / (float)fc.num_of_lights;
         vec3 ldir, lcol;
-        const pt_light light = load_light(sc, li);
-        light_ray(light, intersection, ldir, lcol);
+        bool cone_terms_staged;
+        const pt_light light = load_light(sc, li, cone_terms_staged);
+        light_ray(light, intersection, ldir, lcol, cone_terms_staged);
         vec3 contrib = v3(0);
         if (any_gt0(lcol)) {
             float bp = 0;
