@@ -11,6 +11,7 @@
 
 __device__ __forceinline__ uint32_t pcg(uint32_t& s) { s = s * 747796405u + 2891336453u; uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u; return (w >> 22u) ^ w; }
 
+// BYTES == 32: two 16-B pieces of ONE random 128-B-aligned block (offsets 0 and 64): does the second half of a line cost anything?
 template <int B, int BYTES>
 __global__ __launch_bounds__(256) void k_gather(const char* __restrict__ buf, uint64_t sectors, int rounds, uint32_t* __restrict__ out) {
     extern __shared__ int lds_pad[];
@@ -19,8 +20,14 @@ __global__ __launch_bounds__(256) void k_gather(const char* __restrict__ buf, ui
     for (int r = 0; r < rounds; r++) {
         uint64_t a[B];
 #pragma unroll
-        for (int k = 0; k < B; k++) { const uint64_t x = ((uint64_t)pcg(s) << 20) ^ pcg(s); a[k] = (x % sectors) * 64u; }
-        if (BYTES == 8) {
+        for (int k = 0; k < B; k++) { const uint64_t x = ((uint64_t)pcg(s) << 20) ^ pcg(s); a[k] = BYTES == 32 ? (x % (sectors / 2)) * 128u : (x % sectors) * 64u; }
+        if (BYTES == 32) {
+            uint4 v[B], w[B];
+#pragma unroll
+            for (int k = 0; k < B; k++) { v[k] = *(const uint4*)(buf + a[k]); w[k] = *(const uint4*)(buf + a[k] + 64); }
+#pragma unroll
+            for (int k = 0; k < B; k++) acc += v[k].x ^ v[k].y ^ w[k].z ^ w[k].w;
+        } else if (BYTES == 8) {
             uint2 v[B];
 #pragma unroll
             for (int k = 0; k < B; k++) v[k] = *(const uint2*)(buf + a[k]);
@@ -65,6 +72,7 @@ int main(int argc, char** argv) {
     for (int w : {2, 6}) {
         run<1, 8>(buf, sectors, w, d_out); run<4, 8>(buf, sectors, w, d_out); run<8, 8>(buf, sectors, w, d_out); run<16, 8>(buf, sectors, w, d_out);
         run<4, 16>(buf, sectors, w, d_out); run<8, 16>(buf, sectors, w, d_out);
+        run<4, 32>(buf, sectors, w, d_out);       // "32-B gathers" = both 64-B halves of one 128-B block per gather
     }
     return 0;
 }
