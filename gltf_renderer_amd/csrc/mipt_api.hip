@@ -377,6 +377,7 @@ public:
             }
             fc.cull_null_shadow = ctx->cull_null_shadow ? 1u : 0u;
             fc.spp = 1; fc.pixel_slots = fc.my_tiles * 256u;
+            fc.div_pixel_slots = FastDiv::make(fc.pixel_slots); fc.div_tiles_x = FastDiv::make(fc.tiles_x);
             fc.seed_step = settings->use_frame_as_seed ? 1u : 0u;
 
             HIPOK(hipEventRecord(ctx->ev_trace[0], ctx->stream));

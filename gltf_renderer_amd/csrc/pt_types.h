@@ -191,6 +191,18 @@ struct SceneRec {
 };
 
 // SceneConstants (PathTracer.lib.hlsl:10-30) plus the tile shard of this rank.
+// x / d for x < 2^31 by a multiplication: mul = ceil(2^(31 + L) / d), L = ceil(log2 d), q = mulhi(x, mul) >> (L - 1) (Granlund-Montgomery
+// round-up: exact for every x below 2^31; checked against x / d in tests/test_host_abi.py).  The kernels divide slot numbers by two
+// per-frame constants in four places per path vertex; the hardware has no integer divider (a udiv is ~35 vector instructions).
+struct FastDiv {
+    uint32_t mul, shift, d;
+    static FastDiv make(uint32_t d) {                      // host
+        FastDiv f; f.d = d; f.mul = 0; f.shift = 0;
+        if (d > 1) { uint32_t L = 0; while (((uint64_t)1 << L) < d) L++; f.mul = (uint32_t)((((uint64_t)1 << (31 + L)) + d - 1) / d); f.shift = L - 1; }
+        return f;
+    }
+};
+
 struct FrameConstants {
     float clip_to_world[16];
     float camera_pos[3];
@@ -211,6 +223,7 @@ struct FrameConstants {
     // `spp` consecutive PathtraceScene calls: sample k uses seed + k * seed_step and blends with accumulated_frames + k.
     uint32_t spp, pixel_slots, seed_step;
     uint32_t cull_null_shadow;       // pt_set_null_shadow_culling: do not trace a shadow ray whose pending term is exactly zero
+    FastDiv div_pixel_slots, div_tiles_x;   // divisions by pixel_slots / tiles_x (slot_pixel, slot_sample)
 };
 
 struct Counters {

@@ -262,13 +262,14 @@ PT_DEV void write_pixel(const FrameConstants& fc, int accumulated, float4* __res
 
 // tile-sharded pixel of a (rank-local) slot: slot -> (tile of this rank, lane in tile), one wave64 per 8x8 quadrant
 // sample index of a slot in a sample batch (0 when spp == 1), and the seed that sample draws with
-PT_DEV uint32_t slot_sample(const FrameConstants& fc, uint32_t slot) { return fc.spp > 1 ? slot / fc.pixel_slots : 0u; }
+PT_DEV uint32_t fast_div(const FastDiv& f, uint32_t x) { return f.d == 1u ? x : (__umulhi(x, f.mul) >> f.shift); }      // x < 2^31 (pt_types.h FastDiv)
+PT_DEV uint32_t slot_sample(const FrameConstants& fc, uint32_t slot) { return fc.spp > 1 ? fast_div(fc.div_pixel_slots, slot) : 0u; }
 PT_DEV uint32_t sample_seed(const FrameConstants& fc, uint32_t sample) { return fc.seed + sample * fc.seed_step; }
 PT_DEV bool slot_pixel(const FrameConstants& fc, uint32_t slot, uint32_t& px, uint32_t& py) {
-    if (fc.spp > 1) slot -= (slot / fc.pixel_slots) * fc.pixel_slots;
+    if (fc.spp > 1) slot -= fast_div(fc.div_pixel_slots, slot) * fc.pixel_slots;
     const uint32_t local_tile = slot >> 8, t = slot & 255;
     const uint32_t tile = fc.tile_rank + local_tile * fc.tile_rank_count;
-    const uint32_t tx = tile % fc.tiles_x, ty = tile / fc.tiles_x;
+    const uint32_t ty = fast_div(fc.div_tiles_x, tile), tx = tile - ty * fc.tiles_x;
     const uint32_t wave = t >> 6, lane = t & 63;
     px = tx * PT_TILE + (wave & 1) * 8 + (lane & 7);
     py = ty * PT_TILE + (wave >> 1) * 8 + (lane >> 3);

@@ -182,3 +182,48 @@ int main(void) { int b = check(255, 65535) + check(1023, 65535) + check(65535, 6
     exe = tmp_path / "divc"
     subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), str(src), "-lm"])
     assert subprocess.run([str(exe)], capture_output=True, text=True).stdout.strip() == "0"
+
+
+def test_reciprocal_division_of_slot_numbers_is_exact(tmp_path):
+    """pt_types.h FastDiv (the kernels' slot / pixel_slots and tile / tiles_x): mulhi(x, ceil(2^(31+L) / d)) >> (L - 1) must equal x / d for
+    every x below 2^31.  The struct's own host constructor is compiled from the header; divisors = frame sizes the configs produce plus
+    the awkward ones (1, powers of two and their neighbours, the largest)."""
+    import shutil, subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    src = tmp_path / "fastdiv.cpp"
+    src.write_text(r'''
+#include <cstdint>
+#include <cstdio>
+struct float2 { float x, y; }; struct float4 { float x, y, z, w; }; struct uint2 { unsigned x, y; }; struct uint4 { unsigned x, y, z, w; };
+#define PT_TYPES_HOST_TEST 1
+#include "pt_types_fastdiv.h"
+static uint32_t dv(const FastDiv& f, uint32_t x) { return f.d == 1u ? x : (uint32_t)(((uint64_t)x * f.mul) >> 32) >> f.shift; }
+int main() {
+    const uint32_t ds[] = {1, 2, 3, 5, 7, 8, 15, 16, 17, 120, 240, 64, 255, 256, 257, 1000, 8160u * 256u, 32400u * 256u, 4096u * 256u, 65535, 65536, 65537,
+                           1u << 20, (1u << 20) + 1, 0x7fffffffu, 0x40000000u, 0x40000001u, 12345679u};
+    unsigned long long bad = 0;
+    for (uint32_t d : ds) {
+        const FastDiv f = FastDiv::make(d);
+        for (uint64_t x = 0; x < 0x80000000ull; x++) {
+            if (dv(f, (uint32_t)x) != (uint32_t)x / d) bad++;
+            if (x > 2000000 && x < 0x7ffe0000ull) x += 1021;          // dense at both ends, a stride in between
+        }
+        for (uint64_t k = 1; k * d < 0x80000000ull && k < 200000; k++) {   // and around every multiple of d
+            const uint32_t m = (uint32_t)(k * d);
+            if (dv(f, m) != m / d || dv(f, m - 1) != (m - 1) / d) bad++;
+        }
+    }
+    printf("%llu\n", bad);
+    return bad != 0;
+}
+''')
+    # the struct, cut from the header so that the test compiles exactly what the library compiles
+    import re
+    hdr = open(os.path.join(ROOT, "gltf_renderer_amd", "csrc", "pt_types.h")).read()
+    m = re.search(r"struct FastDiv \{.*?\n\};", hdr, re.S)
+    assert m, "FastDiv not found in pt_types.h"
+    (tmp_path / "pt_types_fastdiv.h").write_text(m.group(0) + "\n")
+    exe = tmp_path / "fastdiv"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", str(tmp_path), "-o", str(exe), str(src)])
+    assert subprocess.run([str(exe)], capture_output=True, text=True).stdout.strip() == "0"
