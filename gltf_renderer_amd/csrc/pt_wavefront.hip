@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_generate(FrameConstants fc, WfBuf
 // Wave-persistent "while-while" traversal of one shard segment with dynamic ray fetch (pt_traverse.h).
 // MODE 0: closest hits of queue `cur` -> wf.hit.  MODE 1: occlusion of the shadow queue -> pend_*.w.
 #ifndef PT_REFILL
-#define PT_REFILL 48          // idle lanes that trigger a refill from the shard queue (swept 8..64 on MI355X: 48 is best)
+#define PT_REFILL 32          // idle lanes that trigger a refill from the shard queue (swept 8..64 on MI355X: 48 was best in round 1; re-swept after the sample pre-pass: 16 / 24 / 32 / 40 / 48 / 56 -> 5470 / 5507 / 5538 / 5536 / 5500 / 5275 Mrays/s)
 #endif
 PT_DEV int shadow_counter(int bounce) { return (bounce & 1) ? 5 : 2; }
 template <bool COUNT, int MODE>
