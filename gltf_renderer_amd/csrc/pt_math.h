@@ -46,6 +46,39 @@ PT_DEV vec3 v3(float x, float y, float z) { return {x, y, z}; }
 PT_DEV vec3 v3p(const float* p) { return {p[0], p[1], p[2]}; }
 PT_DEV vec3 xyz(vec4 v) { return {v.x, v.y, v.z}; }
 
+// fp32 division.  The compiler's IEEE sequence is eleven instructions (2 x v_div_scale, v_rcp, six fma-class, v_div_fmas, v_div_fixup:
+// ~48 issue cycles of a lone wave, the transcendental counts double) and a hit's shading runs ~150 of them -- 11 % of the shade stage
+// (measured with -fno-hip-fp32-correctly-rounded-divide-sqrt, which is NOT used: its 2.5-ulp quotients doubled the share of pixel-samples
+// that part from the oracle and broke the exact white furnace).  fdiv() is the same Newton-Raphson core without the operand scaling:
+// rcp, one correction of the reciprocal, one of the quotient, then v_div_fixup for the special operands (zero, infinity, NaN).  It is
+// BIT-IDENTICAL to a / b whenever divisor, dividend and quotient are normal numbers (tools/probes/lean_div_probe.hip: 0 mismatches in
+// 8.4e9 random operand pairs over exponents -60..60); only a subnormal divisor or a quotient below 2^-126 is not correctly rounded.
+// A vector divided by one scalar corrects the reciprocal once.  PT_EXACT_DIV=1 restores the compiler's sequence everywhere (A/B).
+#ifndef PT_EXACT_DIV
+#define PT_EXACT_DIV 0
+#endif
+PT_DEV float frcp_refined(float b) {                 // 1 / b to within half an ulp (not always the rounded reciprocal; fdiv_with corrects the quotient)
+    float r = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+PT_DEV float fdiv_with(float a, float b, float r) {  // a / b given r = frcp_refined(b), or the rounded 1 / b of a constant b
+#if PT_EXACT_DIV
+    return a / b;
+#else
+    const float q = a * r;
+    const float m = __builtin_fmaf(-b, q, a);
+    return __builtin_amdgcn_div_fixupf(__builtin_fmaf(m, r, q), b, a);
+#endif
+}
+PT_DEV float fdiv(float a, float b) {
+#if PT_EXACT_DIV
+    return a / b;
+#else
+    return fdiv_with(a, b, frcp_refined(b));
+#endif
+}
+
 PT_DEV vec2 operator+(vec2 a, vec2 b) { return {a.x + b.x, a.y + b.y}; }
 PT_DEV vec2 operator-(vec2 a, vec2 b) { return {a.x - b.x, a.y - b.y}; }
 PT_DEV vec2 operator*(vec2 a, float b) { return {a.x * b, a.y * b}; }
@@ -54,11 +87,11 @@ PT_DEV vec2 operator*(float a, vec2 b) { return {a * b.x, a * b.y}; }
 PT_DEV vec3 operator+(vec3 a, vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 PT_DEV vec3 operator-(vec3 a, vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 PT_DEV vec3 operator*(vec3 a, vec3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
-PT_DEV vec3 operator/(vec3 a, vec3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+PT_DEV vec3 operator/(vec3 a, vec3 b) { return {fdiv(a.x, b.x), fdiv(a.y, b.y), fdiv(a.z, b.z)}; }
 PT_DEV vec3 operator+(vec3 a, float b) { return {a.x + b, a.y + b, a.z + b}; }
 PT_DEV vec3 operator-(vec3 a, float b) { return {a.x - b, a.y - b, a.z - b}; }
 PT_DEV vec3 operator*(vec3 a, float b) { return {a.x * b, a.y * b, a.z * b}; }
-PT_DEV vec3 operator/(vec3 a, float b) { return {a.x / b, a.y / b, a.z / b}; }
+PT_DEV vec3 operator/(vec3 a, float b) { const float r = frcp_refined(b); return {fdiv_with(a.x, b, r), fdiv_with(a.y, b, r), fdiv_with(a.z, b, r)}; }
 PT_DEV vec3 operator*(float a, vec3 b) { return {a * b.x, a * b.y, a * b.z}; }
 PT_DEV vec3 operator+(float a, vec3 b) { return {a + b.x, a + b.y, a + b.z}; }
 PT_DEV vec3 operator-(float a, vec3 b) { return {a - b.x, a - b.y, a - b.z}; }
@@ -75,7 +108,7 @@ PT_DEV float dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 PT_DEV vec3 cross(vec3 a, vec3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 PT_DEV float length(vec3 v) { return sqrtf(dot(v, v)); }
 PT_DEV vec3 normalize(vec3 v) { return v / sqrtf(dot(v, v)); }
-PT_DEV vec2 normalize(vec2 v) { float l = sqrtf(dot(v, v)); return {v.x / l, v.y / l}; }
+PT_DEV vec2 normalize(vec2 v) { const float l = sqrtf(dot(v, v)), r = frcp_refined(l); return {fdiv_with(v.x, l, r), fdiv_with(v.y, l, r)}; }
 
 PT_DEV float hmin(float a, float b) { return fminf(a, b); }
 PT_DEV float hmax(float a, float b) { return fmaxf(a, b); }

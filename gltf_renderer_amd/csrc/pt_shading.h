@@ -37,13 +37,14 @@ PT_DEV vec3 decode_octahedral(float ex, float ey) {                // Common.hls
 }
 PT_DEV vec2 encode_octahedral(vec3 n) {                            // Common.hlsli:76-88
     float s = fabsf(n.x) + fabsf(n.y) + fabsf(n.z);
-    float ox = n.x / s, oy = n.y / s, oz = n.z / s;
+    const float rs_ = frcp_refined(s);
+    float ox = fdiv_with(n.x, s, rs_), oy = fdiv_with(n.y, s, rs_), oz = fdiv_with(n.z, s, rs_);
     if (oz >= 0.f) return {ox, oy};
     return {(ox >= 0 ? 1.f : -1.f) * (1.f - fabsf(oy)), (oy >= 0 ? 1.f : -1.f) * (1.f - fabsf(ox))};
 }
 PT_DEV void basis_accurate(vec3 n, vec3& b1, vec3& b2) {           // Common.hlsli:46-53
     float sg = n.z >= 0.0f ? 1.0f : -1.0f;
-    float a = -1.0f / (sg + n.z);
+    float a = fdiv(-1.0f, sg + n.z);
     float b = n.x * n.y * a;
     b1 = v3(1.0f + sg * n.x * n.x * a, sg * b, -sg * n.x);
     b2 = v3(b, sg + n.y * n.y * a, -n.y);
@@ -80,7 +81,7 @@ PT_DEV uint32_t encode_tangent_space(vec3 normal, vec3 tangent, float winding) {
     vec3 ct, cb;
     basis_accurate(nq, ct, cb);
     float angle = atan2f(dot(tangent, cb), dot(tangent, ct));
-    uint32_t qt = f2u(((angle / kTau) + 0.5f) * 1023 + 0.5f);
+    uint32_t qt = f2u((fdiv(angle, kTau) + 0.5f) * 1023 + 0.5f);
     uint32_t qw = winding == 1 ? 3u : 0u;
     return qx | (qy << 10) | (qt << 20) | (qw << 30);
 }
@@ -600,28 +601,28 @@ PT_DEV float ggx_d(float a, float ndh) {                                        
     float a2 = a * a;
     float den = ndh * ndh * (a2 - 1) + 1;
     den *= kPi * den;
-    return a2 * heavyside(ndh) / den;
+    return fdiv(a2 * heavyside(ndh), den);
 }
 PT_DEV float ggx_corr_v(float a, float ndl, float ndv, float hdl, float hdv) {                                 // :78-85
     float a2 = a * a;
     float num = 0.5f * heavyside(hdl) * heavyside(hdv);
     float den = fabsf(ndv) * sqrtf(a2 + (1 - a2) * ndl * ndl);
     den += fabsf(ndl) * sqrtf(a2 + (1 - a2) * ndv * ndv);
-    return num / den;
+    return fdiv(num, den);
 }
 PT_DEV float specular_brdf(float a, float ndl, float ndv, float ndh, float hdl, float hdv) { return ggx_corr_v(a, ndl, ndv, hdl, hdv) * ggx_d(a, ndh); }  // :87-90
 PT_DEV float ggx_aniso_d(float ax, float ay, vec3 h) {                                                         // :93-99
     float a2 = ax * ay;
     vec3 f = v3(ay * h.x, ax * h.y, a2 * h.z);
-    float w2 = a2 / dot(f, f);
-    return heavyside(h.z) * a2 * w2 * w2 / kPi;
+    float w2 = fdiv(a2, dot(f, f));
+    return fdiv(heavyside(h.z) * a2 * w2 * w2, kPi);
 }
 PT_DEV float aniso_specular_brdf(float ax, float ay, vec3 v, vec3 h, vec3 l) {                                 // :117-130
     float hdv = dot(h, v), hdl = dot(h, l);
     float num = 0.5f * heavyside(hdv) * heavyside(hdl);
     float vv = fabsf(l.z) * length(v3(ax * v.x, ay * v.y, v.z));
     float ll = fabsf(v.z) * length(v3(ax * l.x, ay * l.y, l.z));
-    return (num / (vv + ll)) * ggx_aniso_d(ax, ay, h);
+    return fdiv(num, vv + ll) * ggx_aniso_d(ax, ay, h);
 }
 PT_DEV float fresnel_coat_w(float weight, float ndv) {            // FresnelCoat's lerp factor, IOR 1.5 (:157-163)
     float f0 = (1 - 1.5f) / (1 + 1.5f);
@@ -632,18 +633,18 @@ PT_DEV float sheen_l(float alpha, float x) {                                    
     float t = (1 - alpha) * (1 - alpha);
     float a = lerpf(21.5473f, 25.3245f, t), b = lerpf(3.82987f, 3.32435f, t), c = lerpf(0.19823f, 0.16801f, t);
     float d = lerpf(-1.97760f, -1.27393f, t), e = lerpf(-4.32054f, -4.85967f, t);
-    return a / (1 + b * hpow(x, c)) + d * x + e;
+    return fdiv(a, 1 + b * hpow(x, c)) + d * x + e;
 }
 PT_DEV float sheen_shadowing(float alpha, float c) {                                                           // :186-193
     if (c < 0.5f) return expf(sheen_l(alpha, c));
     return expf(2 * sheen_l(alpha, 0.5f) - sheen_l(alpha, 1 - c));
 }
 PT_DEV float sheen_brdf(float alpha, float ndl, float ndv, float ndh) {                                        // :166-173,195-203
-    float inv_r = 1 / alpha;
+    float inv_r = fdiv(1.0f, alpha);
     float sin2h = 1 - ndh * ndh;
-    float d = (2 + inv_r) * hpow(sin2h, inv_r * 0.5f) / (2 * kPi);
+    float d = fdiv((2 + inv_r) * hpow(sin2h, inv_r * 0.5f), 2 * kPi);
     // SheenBrdf passes (n_dot_v, n_dot_l) into SheenVisibility(alpha, n_dot_l, n_dot_v): swapped names, same product
-    float vis = clampf(1 / ((1 + sheen_shadowing(alpha, ndv) + sheen_shadowing(alpha, ndl)) * 4 * ndv * ndl), 0, 1);
+    float vis = clampf(fdiv(1.0f, (1 + sheen_shadowing(alpha, ndv) + sheen_shadowing(alpha, ndl)) * 4 * ndv * ndl), 0, 1);
     return d * vis;
 }
 PT_DEV float sheen_e(const float* lut, float alpha, float cos_theta) {   // Bsdf.hlsli:204-208: bilinear, clamp, 16x16
@@ -683,7 +684,7 @@ PT_DEV vec3 gltf_bsdf(const float* lut, const Surface& s, vec3 v, vec3 l, int mo
 #endif
     diffuse = lerp3(diffuse, transmission, s.transmissive);
     // FresnelMix :137-144
-    float f0s = (1 - s.ior) / (1 + s.ior);
+    float f0s = fdiv(1 - s.ior, 1 + s.ior);
     vec3 f0 = v3(f0s);
     f0 *= f0 * s.spec_color;
     f0 = hmin(f0, v3(1));
@@ -717,13 +718,13 @@ PT_DEV vec2 uv_to_square(vec2 uv) { return {uv.x * 2 + -1, uv.y * -2 + 1}; }    
 PT_DEV vec2 square_to_uv(vec2 s) { return {(s.x - -1) * 0.5f, (s.y - 1) * -0.5f}; }                            // :57-60
 PT_DEV vec2 square_to_disk(vec2 s) {                                                                           // :83-90
     float r = hmax(fabsf(s.x), fabsf(s.y));
-    float phi = r == 0 ? 0 : (kPi * (r + (fabsf(s.y) - fabsf(s.x))) / (4 * r));
+    float phi = r == 0 ? 0 : fdiv(kPi * (r + (fabsf(s.y) - fabsf(s.x))), 4 * r);
     return {signf(s.x) * r * cosf(phi), signf(s.y) * r * sinf(phi)};
 }
 PT_DEV vec3 square_to_sphere(vec2 s) {                                                                         // :124-136
     float d = 1 - (fabsf(s.x) + fabsf(s.y));
     float r = 1 - fabsf(d);
-    float phi = (r == 0) ? 0 : (kPi / 4) * ((fabsf(s.y) - fabsf(s.x)) / r + 1);
+    float phi = (r == 0) ? 0 : (kPi / 4) * (fdiv(fabsf(s.y) - fabsf(s.x), r) + 1);
     float f = r * sqrtf(2 - r * r);
     return {f * signf(s.x) * cosf(phi), f * signf(s.y) * sinf(phi), signf(d) * (1 - r * r)};
 }
@@ -753,10 +754,10 @@ PT_DEV vec3 sample_cosine_hemisphere(vec3 n, float u0, float u1) {              
     float s = sqrtf(1.0f - y * y);
     return normalize(n + v3(s * cosf(theta), s * sinf(theta), y));
 }
-PT_DEV float cosine_hemisphere_pdf(vec3 n, vec3 v) { return saturate(dot(v, n) / kPi); }                       // :35-38
+PT_DEV float cosine_hemisphere_pdf(vec3 n, vec3 v) { return saturate(fdiv(dot(v, n), kPi)); }                       // :35-38
 PT_DEV vec3 sample_ggx_normal(float a, float u0, float u1) {                                                   // :41-52
     float phi = kTau * u0;
-    float ct = sqrtf((1 - u1) / (1 + (a * a - 1) * u1));
+    float ct = sqrtf(fdiv(1 - u1, 1 + (a * a - 1) * u1));
     float st = sqrtf(1 - ct * ct);
     return {st * cosf(phi), st * sinf(phi), ct};
 }
@@ -789,7 +790,7 @@ PT_DEV float transmission_pdf(const Surface& s, vec3 v, vec3 l) {               
     l = l - 2 * dot(s.n, l) * s.n;
     vec3 h = normalize(v + l);
     float pdf = ggx_normal_pdf(a, s.n, h);
-    pdf /= 4 * dot(v, h);
+    pdf = fdiv(pdf, 4 * dot(v, h));
     return pdf;
 }
 PT_DEV float bsdf_pdf(const Surface& s, vec3 v, vec3 l, bool is_transmission, const Lobes& p) {               // :555-565
@@ -797,13 +798,13 @@ PT_DEV float bsdf_pdf(const Surface& s, vec3 v, vec3 l, bool is_transmission, co
     vec3 h = normalize(v + l);
     float vdh4 = 4 * dot(v, h);
     float cc = ggx_normal_pdf(s.cc_rough, s.cc_n, h);                                                        // ClearcoatPdf :408-416
-    cc /= vdh4;
+    cc = fdiv(cc, vdh4);
     float pdf = p.clearcoat * cc;
     float cosp = cosine_hemisphere_pdf(s.n, l);
     pdf += p.sheen * cosp;                                                                                   // SheenPdf :423-426
     vec3 lh = to_local(s.at, s.ab, s.n, h);                                                                  // SpecularPdf :444-460
     float sp = ggx_aniso_d(s.ax, s.ay, lh) * lh.z;
-    sp /= vdh4;
+    sp = fdiv(sp, vdh4);
     pdf += p.specular * sp;
     pdf += p.diffuse * cosp;                                                                                 // DiffusePdf :467-470
     return pdf;
@@ -811,8 +812,8 @@ PT_DEV float bsdf_pdf(const Surface& s, vec3 v, vec3 l, bool is_transmission, co
 PT_DEV vec3 evaluate_bsdf(uint32_t flags, const float* lut, const Surface& s, const Lobes& p, vec3 ng, vec3 v, vec3 l, float& pdf) {   // :567-593
     if (flags & PT_FLAG_MATERIAL_DIFFUSE_WHITE) {
         float ndl = saturate(dot(s.n, l));
-        pdf = ndl / kPi;
-        return v3(ndl / kPi);
+        pdf = fdiv(ndl, kPi);
+        return v3(fdiv(ndl, kPi));
     }
     if (flags & PT_FLAG_MATERIAL_MIS) {
         bool is_transmission = (dot(ng, l) * dot(ng, v)) < 0;
@@ -820,7 +821,7 @@ PT_DEV vec3 evaluate_bsdf(uint32_t flags, const float* lut, const Surface& s, co
         return s.alpha * gltf_bsdf(lut, s, v, l, is_transmission ? 2 : 1);
     }
     float ndl = saturate(dot(s.n, l));
-    pdf = ndl / kPi;
+    pdf = fdiv(ndl, kPi);
     pdf *= s.alpha;
     return s.alpha * gltf_bsdf(lut, s, v, l, 0);
 }
@@ -830,7 +831,7 @@ PT_DEV vec3 sample_bsdf(uint32_t flags, const float* lut, const Surface& s, cons
         use_mis = true; is_transmission = false;
         l = sample_cosine_hemisphere(s.n, u.y, u.z);
         pdf = cosine_hemisphere_pdf(s.n, l);
-        return v3(dot(s.n, l) / kPi);
+        return v3(fdiv(dot(s.n, l), kPi));
     }
     if (flags & PT_FLAG_MATERIAL_MIS) {
         is_transmission = false; use_mis = true;
@@ -891,7 +892,7 @@ static __shared__ float4 pt_lds_light[kLightCacheMax * 4];
 // staged light, by the expressions light_ray() uses, and kept in the record's two padding floats of the LDS copy: every wave holds a
 // lane that picked the spot light, so every hit used to pay for them.
 PT_DEV void spot_cone_terms(float inner_angle, float outer_angle, float& scale, float& offset) {
-    scale = 1.0f / hmax(0.001f, cosf(inner_angle) - cosf(outer_angle));
+    scale = fdiv(1.0f, hmax(0.001f, cosf(inner_angle) - cosf(outer_angle)));
     offset = -cosf(outer_angle) * scale;
 }
 PT_DEV void stage_lights(const SceneRec& sc, int num_of_lights) {   // 256-thread workgroups
@@ -919,7 +920,7 @@ PT_DEV pt_light load_light(const SceneRec& sc, uint32_t li, bool& cone_terms_sta
 }
 #else
 PT_DEV void spot_cone_terms(float inner_angle, float outer_angle, float& scale, float& offset) {
-    scale = 1.0f / hmax(0.001f, cosf(inner_angle) - cosf(outer_angle));
+    scale = fdiv(1.0f, hmax(0.001f, cosf(inner_angle) - cosf(outer_angle)));
     offset = -cosf(outer_angle) * scale;
 }
 PT_DEV void stage_lights(const SceneRec&, int) {}
@@ -934,8 +935,8 @@ PT_DEV void light_ray(const pt_light& light, vec3 p, vec3& dir, vec3& color, boo
     if (local) {
         float distance = length(dir);
         float falloff = 1.0f;
-        if (light.cutoff > 0.0f) falloff = hmax(hmin(1.0f - hpow(distance / light.cutoff, 4.0f), 1.0f), 0.0f);
-        falloff /= distance * distance;
+        if (light.cutoff > 0.0f) falloff = hmax(hmin(1.0f - hpow(fdiv(distance, light.cutoff), 4.0f), 1.0f), 0.0f);
+        falloff = fdiv(falloff, distance * distance);
         color *= falloff;
     }
     dir = normalize(dir);
@@ -956,8 +957,9 @@ PT_DEV void dir_to_face(vec3 d, int& face, float& u, float& v) {   // D3D major-
     if (ax >= ay && ax >= az) { ma = ax; if (d.x >= 0) { face = 0; sc = -d.z; tc = -d.y; } else { face = 1; sc = d.z; tc = -d.y; } }
     else if (ay >= az) { ma = ay; if (d.y >= 0) { face = 2; sc = d.x; tc = d.z; } else { face = 3; sc = d.x; tc = -d.z; } }
     else { ma = az; if (d.z >= 0) { face = 4; sc = d.x; tc = -d.y; } else { face = 5; sc = -d.x; tc = -d.y; } }
-    u = 0.5f * (sc / ma + 1.0f);
-    v = 0.5f * (tc / ma + 1.0f);
+    const float rma_ = frcp_refined(ma);
+    u = 0.5f * (fdiv_with(sc, ma, rma_) + 1.0f);
+    v = 0.5f * (fdiv_with(tc, ma, rma_) + 1.0f);
 }
 PT_DEV vec3 cube_texel(const uint16_t* cube, int n, int face, int i, int j) {
     const uint2 q = *(const uint2*)(cube + (((size_t)face * n + j) * n + i) * 4);     // 8-B RGBA16F texel
@@ -968,7 +970,7 @@ PT_DEV vec3 cube_texel(const uint16_t* cube, int n, int face, int i, int j) {
 // issued together afterwards.
 PT_DEV size_t cube_tap_index(int n, int face, int i, int j) {
     if (!(i >= 0 && i < n && j >= 0 && j < n)) {
-        vec3 d = cubemap_to_direction(face, ((float)i + 0.5f) / (float)n, ((float)j + 0.5f) / (float)n);
+        vec3 d = cubemap_to_direction(face, fdiv((float)i + 0.5f, (float)n), fdiv((float)j + 0.5f, (float)n));
         float u, v;
         dir_to_face(d, face, u, v);
         i = (int)floorf(u * (float)n); j = (int)floorf(v * (float)n);
@@ -1004,12 +1006,12 @@ PT_DEV float imp_load(const EnvRec& e, int level, uint32_t x, uint32_t y) {
 // chosen column, re-normalising the random numbers.  sx/sy = 1 for right / lower.
 PT_DEV void importance_step(float ul, float ur, float ll, float lr, float& ux, float& uy, uint32_t& sx, uint32_t& sy) {
     const float left = ul + ll, right = ur + lr, total = left + right;
-    const float prob_left = left / total;
+    const float prob_left = fdiv(left, total);
     const bool go_left = ux < prob_left;
-    ux = (go_left ? ux : ux - prob_left) / (go_left ? prob_left : 1 - prob_left);
-    const float prob_upper = (go_left ? ul : ur) / (go_left ? left : right);
+    ux = fdiv(go_left ? ux : ux - prob_left, go_left ? prob_left : 1 - prob_left);
+    const float prob_upper = fdiv(go_left ? ul : ur, go_left ? left : right);
     const bool up = uy < prob_upper;
-    uy = (up ? uy : uy - prob_upper) / (up ? prob_upper : 1 - prob_upper);
+    uy = fdiv(up ? uy : uy - prob_upper, up ? prob_upper : 1 - prob_upper);
     sx = go_left ? 0u : 1u;
     sy = up ? 0u : 1u;
 }
@@ -1064,8 +1066,8 @@ PT_DEV vec2 sample_importance_map(const EnvRec& e, float ux, float uy, float& pd
         py = (py << 2) | (sy << 1) | ty;
     }
     float w = (float)e.imp_res;
-    pdf = w * w * value / e.imp_total;                          // value = level-0 texel (px, py); imp_total = mips[10][0]
-    return {((float)px + ux) / w, ((float)py + uy) / w};      // both axes / width (quirk q10)
+    pdf = fdiv(w * w * value, e.imp_total);                          // value = level-0 texel (px, py); imp_total = mips[10][0]
+    return {fdiv((float)px + ux, w), fdiv((float)py + uy, w)};      // both axes / width (quirk q10)
 }
 // SampleEnvironmentMap's hit-independent half (PathTracer.lib.hlsl:688-703): direction, solid-angle pdf and radiance of the sample
 // the random numbers (u0, u1) pick.  It depends on the pixel's random sequence only, never on the hit, which is what lets the
@@ -1077,7 +1079,7 @@ PT_DEV EnvSample environment_light_sample(const SceneRec& sc, float environment_
     if (sc.has_env) {
         vec2 uv = sample_importance_map(sc.env, u0, u1, e.pdf, lds_top);
         e.dir = square_to_sphere(uv_to_square(uv));
-        e.pdf /= 4 * kPi;
+        e.pdf = fdiv(e.pdf, 4 * kPi);
         e.color = environment_intensity * sample_cube(sc.env.cube, sc.env.cube_n, e.dir);
     }
     return e;
@@ -1087,7 +1089,7 @@ PT_DEV float importance_map_pdf(const EnvRec& e, vec2 uv) {                     
     float r = (float)e.imp_res;
     int px = f2i(floorf(uv.x * r) - .5f), py = f2i(floorf(uv.y * r) - .5f);       // UVToPixel: off by one (quirk q9)
     float value = (px < 0 || py < 0) ? 0.f : imp_load(e, 0, (uint32_t)px, (uint32_t)py);
-    return r * r * value / total;
+    return fdiv(r * r * value, total);
 }
 
 // ---------------------------------------------------------------- misc

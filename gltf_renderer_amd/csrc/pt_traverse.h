@@ -71,7 +71,7 @@ struct Trav {
 
 PT_DEV void trav_init(Trav& t, const SceneRec& sc, const Ray& r, uint32_t rf, uint32_t mask, int mode, float transmission0) {
     t.o = r.o; t.d = r.d; t.tmin = r.tmin; t.tmax = r.tmax;
-    t.inv = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    t.inv = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);           // the compiler's full division: a subnormal direction component must give infinity, not NaN
     t.ood = v3(r.o.x * t.inv.x, r.o.y * t.inv.y, r.o.z * t.inv.z);
     t.rf = rf; t.mask = mask; t.mode = mode;
     t.all_candidates = (mode == 1) && (rf & RF_FORCE_NON_OPAQUE);

@@ -34,8 +34,8 @@ PT_DEV vec3 shade_miss(const SceneRec& sc, const FrameConstants& fc, vec3 dir, c
     if (flags & PT_FLAG_ENVIRONMENT_MAP) {
         c = sc.has_env ? fc.environment_intensity * sample_cube(sc.env.cube, sc.env.cube_n, dir) : v3(0);
         if ((flags & PT_FLAG_ENVIRONMENT_MIS) && ps.prev_mis) {
-            float env_pdf = sc.has_env ? importance_map_pdf(sc.env, square_to_uv(sphere_to_square(normalize(dir)))) / (4 * kPi) : 0.f;
-            c *= ps.prev_pdf / (ps.prev_pdf + env_pdf);                                              // BalanceHeuristic :383-386
+            float env_pdf = sc.has_env ? fdiv(importance_map_pdf(sc.env, square_to_uv(sphere_to_square(normalize(dir)))), 4 * kPi) : 0.f;
+            c *= fdiv(ps.prev_pdf, ps.prev_pdf + env_pdf);                                              // BalanceHeuristic :383-386
         }
     } else c = fc.environment_intensity * v3p(fc.environment_color);
     return ps.beta * c;
@@ -135,7 +135,7 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
         if (any_gt0(lcol)) {
             float bp = 0;
             vec3 f = evaluate_bsdf(flags, sc.sheen_e, sp, lobes, va.ng, view, ldir, bp);
-            float mis = light_pdf / (light_pdf + bp);
+            float mis = fdiv(light_pdf, light_pdf + bp);
             contrib = (mis * f * lcol) / light_pdf;
         }
         if (flags & PT_FLAG_INDIRECT_ENVIRONMENT_ONLY) c += contrib;                                 // TraceShadowRay returns 1 untraced (:726-728)
@@ -153,7 +153,7 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
         float u = next_random(px, py, seed, ps.rc).x;
         uint32_t li = f2u(u * (float)fc.num_of_lights);
         li = min(li, (uint32_t)(fc.num_of_lights - 1));                                              // u may be exactly 1 (quirk q17)
-        float pdf = 1.0f / (float)fc.num_of_lights;
+        float pdf = fdiv(1.0f, (float)fc.num_of_lights);
         vec3 ldir, lcol;
         bool cone_terms_staged;
         const pt_light light = load_light(sc, li, cone_terms_staged);
@@ -224,8 +224,8 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
 PT_DEV Ray camera_ray(const FrameConstants& fc, uint32_t seed, uint32_t px, uint32_t py, int& rc) {
     vec4 r = next_random(px, py, seed, rc);
     float jx = r.x - 0.5f, jy = r.y - 0.5f;
-    float cx = (((float)px + 0.5f + jx) / (float)fc.res_x) * 2 - 1;
-    float cy = (((float)py + 0.5f + jy) / (float)fc.res_y) * 2 - 1;
+    float cx = fdiv((float)px + 0.5f + jx, (float)fc.res_x) * 2 - 1;
+    float cy = fdiv((float)py + 0.5f + jy, (float)fc.res_y) * 2 - 1;
     cy = -cy;
     vec4 s = mul4(fc.clip_to_world, vec4{cx, cy, 1, 1});
     vec4 e = mul4(fc.clip_to_world, vec4{cx, cy, 0, 1});
@@ -244,13 +244,13 @@ PT_DEV vec3 sanitize_sample(const FrameConstants& fc, vec3 L) {
     if (any_inf(L)) L = (flags & PT_FLAG_SHOW_INF) ? v3(1, 0, 0) : v3(0);
     if (flags & PT_FLAG_LUMINANCE_CLAMP) {
         float lum = luminance(L);
-        if (lum > fc.luminance_clamp) L *= fc.luminance_clamp / lum;
+        if (lum > fc.luminance_clamp) L *= fdiv(fc.luminance_clamp, lum);
     }
     return L;
 }
 // the running mean: `h` is the pixel with `accumulated` frames in it
 PT_DEV float4 blend_sample(float4 h, int accumulated, vec3 L) {
-    float blend = 1.0f / ((float)accumulated + 1.0f);
+    float blend = fdiv(1.0f, (float)accumulated + 1.0f);
     return make_float4(h.x + blend * (L.x - h.x), h.y + blend * (L.y - h.y), h.z + blend * (L.z - h.z), h.w + blend * (1.0f - h.w));
 }
 PT_DEV void write_pixel(const FrameConstants& fc, int accumulated, float4* __restrict__ output, uint32_t px, uint32_t py, vec3 L) {
