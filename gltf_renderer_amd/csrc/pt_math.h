@@ -120,7 +120,17 @@ PT_DEV float lerpf(float a, float b, float t) { return a + t * (b - a); }
 PT_DEV vec3 lerp3(vec3 a, vec3 b, float t) { return a + t * (b - a); }
 PT_DEV float signf(float x) { return x > 0 ? 1.0f : (x < 0 ? -1.0f : 0.0f); }
 PT_DEV vec3 reflect(vec3 i, vec3 n) { return i - 2 * dot(n, i) * n; }
+// pow(x, y) = exp2(y * log2 x).  The library's exp2f / log2f are v_exp_f32 / v_log_f32 wrapped in range scaling for
+// subnormal arguments and results (9 + 8 instructions); the bare instructions give the same bits everywhere else and flush those to
+// zero -- Schlick's (1 - c)^5 below 2^-126.  PT_LIBM_POW=1 keeps the library calls (A/B, tools/compare_builds.py).
+#ifndef PT_LIBM_POW
+#define PT_LIBM_POW 0
+#endif
+#if PT_LIBM_POW
 PT_DEV float hpow(float x, float y) { return exp2f(y * log2f(x)); }
+#else
+PT_DEV float hpow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+#endif
 PT_DEV float max3(vec3 c) { return fmaxf(fmaxf(c.x, c.y), c.z); }
 PT_DEV bool any_gt0(vec3 v) { return v.x > 0 || v.y > 0 || v.z > 0; }
 PT_DEV bool any_nan(vec3 v) { return (v.x != v.x) || (v.y != v.y) || (v.z != v.z); }
