@@ -111,6 +111,7 @@ PT_DEV void trav_pop(Trav& t, const int* lds_stack, const int* spill) {
 // On exit t.cur is the nearest hit child, or the popped entry, or kTravDone.
 template <bool COUNT, bool ORDERED = true>
 PT_DEV void trav_node_step(Trav& t, const SceneRec& sc, int* lds_stack, int* spill, LaneStats& st) {
+#pragma clang fp contract(fast)       // box tests only decide the visiting order: fused multiply-adds here cannot change a hit (csrc/Makefile)
     const float4* np = (const float4*)sc.nodes + (size_t)t.cur * kNodeFloat4;
     const float4 hd = np[0], ca = np[1], cb = np[2], qx = np[3], qy = np[4], qz = np[5];
     if (COUNT) st.nodes++;
@@ -167,6 +168,7 @@ PT_DEV void trav_node_step(Trav& t, const SceneRec& sc, int* lds_stack, int* spi
 // One inner-node step: t.cur >= 0 on entry; on exit t.cur is the nearest hit child, or the popped entry, or kTravDone.
 template <bool COUNT, bool ORDERED = true>
 PT_DEV void trav_node_step(Trav& t, const SceneRec& sc, int* lds_stack, int* spill, LaneStats& st) {
+#pragma clang fp contract(fast)       // box tests only decide the visiting order: fused multiply-adds here cannot change a hit (csrc/Makefile)
     const float4* np = (const float4*)sc.nodes + (size_t)t.cur * 4;
     const float4 hd = np[0], chf = np[1], qxy = np[2];
     const float2 qz = *(const float2*)(np + 3);

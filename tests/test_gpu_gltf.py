@@ -62,7 +62,8 @@ def test_loader_fed_scene_renders_like_the_direct_upload(R, tmp_path):
     b, sb = render_loaded(R, s, path, 16)
     assert sa.bvh_triangles == sb.bvh_triangles
     # same streams up to: node matrices that went through decompose -> T*R*S (1e-7), tangent-space packing on rounding edges
-    assert rel_l2(b, a) <= 5e-3, rel_l2(b, a)
+    print("loader-fed scene against the direct upload: rel L2 %.3e" % rel_l2(b, a))
+    assert rel_l2(b, a) <= 1e-4, rel_l2(b, a)                      # measured 1.8e-6
 
 
 def test_animated_skinned_gltf_drives_the_dynamic_path(R, tmp_path):
@@ -76,7 +77,8 @@ def test_animated_skinned_gltf_drives_the_dynamic_path(R, tmp_path):
     a, _ = render_direct(R, s, 16, prepare)
     b, _ = render_loaded(R, s, path, 16, animate_time=t)
     rest, _ = render_direct(R, s, 16)
-    assert rel_l2(b, a) <= 1e-2, rel_l2(b, a)
+    print("animated glTF against the analytic pose: rel L2 %.3e (bind pose: %.3e)" % (rel_l2(b, a), rel_l2(rest, a)))
+    assert rel_l2(b, a) <= 1e-4, rel_l2(b, a)                      # measured 3.4e-7
     assert rel_l2(rest, a) > 5 * rel_l2(b, a)          # the pose matters: the bind pose is measurably a different image
 
 

@@ -153,12 +153,10 @@ def test_constant_environment_no_envmap(R, oracle_lib):
 def test_material_grid_deep_bounces(R, oracle_lib):
     """config-4 class (transmission / clearcoat / sheen / anisotropy sweeps), 16 bounces with the clamp lifted."""
     import oracle.pyoracle as po
-    # The image metric on THIS scene is decided by single events: smooth transmissive spheres chain many discrete decisions, and a
-    # path that reaches the 2e3-radiance sun on one side only leaves one saturated pixel -- in a 96^2 image that alone is 1e-2
-    # (tools/diag_grid.py: 84 % of the squared error in one 12 x 12 block, no bias: signed mean difference 1e-5 of the mean; measured
-    # 1.36e-3 at 96^2 / 64 spp, 1.14e-3 at 192 spp, 2.8e-3 at 160^2 / 128 spp -- different events each time).  So the north_star bar
-    # is asserted on the image WITHOUT its few event pixels (0.1 % of the pixels), the events themselves are counted and bounded,
-    # and the whole-image figure is printed.  Every other radiance test of this file asserts the plain 1e-3.
+    # Smooth transmissive spheres chain many discrete decisions (lobe pick, roulette), and a path that reaches the 2e3-radiance sun on one
+    # side only leaves a saturated pixel: with an FMA-contracting build this scene sat at 1.1e-3 ... 2.8e-3 (different events each time) and
+    # only its bulk met the bar.  Since the path-tracing kernels are built like the oracle -- no floating-point contraction (csrc/Makefile) --
+    # the WHOLE image meets it: measured 4.8e-5 (1.8e-6 without the 16 worst pixels, no pixel beyond 0.05).  Both figures are asserted.
     p = Pair(R, oracle_lib, scenes.material_grid(128, seg=12))
     og, b = p.render(frames=96)
     ta, tb = p.r.tonemap(og).astype(np.float64), po.tonemap(b).astype(np.float64)
@@ -174,8 +172,8 @@ def test_material_grid_deep_bounces(R, oracle_lib):
           "median |diff| %.2e; relative bias %.2e" % (e, trimmed, k, int((d > 0.05).sum()), float(np.median(d)), bias))
     st = p.r.stats(); c = p.o.counters()
     assert abs(int(st.rays) - c["rays"]) <= 5e-4 * c["rays"]
-    assert trimmed <= 1e-3, (trimmed, e)
-    assert e <= 1e-2 and (d > 0.05).sum() <= 8 and float(np.median(d)) < 1e-5 and abs(bias) < 1e-3, (e, int((d > 0.05).sum()), float(np.median(d)), bias)
+    assert e <= 1e-3, e                                             # the north_star bar, whole image
+    assert trimmed <= 1e-4 and (d > 0.05).sum() <= 2 and float(np.median(d)) < 1e-5 and abs(bias) < 1e-4, (trimmed, int((d > 0.05).sum()), float(np.median(d)), bias)
     p.close()
 
 
@@ -516,18 +514,18 @@ def test_fullsize_scene_hits_and_radiance_match_the_oracle(R, oracle_lib):
         og, b = p.render(settings=st)
         err = np.abs(p.r.readback(og)[..., :3] - b[..., :3]).max(axis=2)
         assert (err > 1e-4).mean() < 0.002, (abi.DEBUG_OUTPUT_NAMES[dbg], float((err > 1e-4).mean()))
-    # Radiance per pixel-sample, seed matched.  The primary hits are identical (above) and first-hit radiance agrees to rounding,
-    # except where this scene amplifies rounding: it tiles its textures (texture coordinates of tens of units, so one ulp of u is
-    # 1e-4 of a texel and the bilinear normal-map weights move by as much between an FMA-contracted and a plain build), and a
-    # light grazing the shading normal turns that into percents of a contribution that is itself ~1e-5 of the image's range
-    # (tools/diag_lights.py, tools/diag_dirlight.py: fully rough materials change nothing, so it is not the specular peak).
-    # Those pixels, and deeper paths whose discrete decisions then flip, are counted and bounded, not hidden.
-    for mb, frac_1pc in ((1, 0.004), (4, 0.03)):
+    # Radiance per pixel-sample, seed matched.  The primary hits are identical (above).  This scene amplifies rounding -- it tiles its textures
+    # (texture coordinates of tens of units) and glossy lobes turn a perturbed shading normal into a different path -- and an FMA-contracting
+    # build parted from the plain-arithmetic oracle in 0.3 % of the pixel-samples at one bounce and 2 % at four.  Built without contraction
+    # (csrc/Makefile) the kernels agree in every pixel-sample at one bounce and in all but 0.04 % at four (the library's sin / cos / exp2 /
+    # log2 are not glibc's); those are counted and bounded, not hidden.
+    for mb, frac_1pc in ((1, 1e-4), (4, 2e-3)):
         st = copy_settings(s.settings); st.max_bounces = mb; st.min_bounces = min(st.min_bounces, mb); st.flags &= ~abi.FLAG_ACCUMULATE
         st.use_frame_as_seed = 0; st.seed = 9
         og, b = p.render(settings=st)
         a = p.r.readback(og)[..., :3].astype(np.float64); bb = b[..., :3].astype(np.float64)
         rel = np.abs(a - bb).max(axis=2) / np.maximum(np.abs(bb).max(axis=2), 1e-6)
+        print("full-size scene, max_bounces %d: pixel-samples beyond 1e-2 of the oracle's: %.5f, median relative difference %.2e" % (mb, float((rel > 1e-2).mean()), float(np.median(rel))))
         assert np.median(rel) < 1e-6 and (rel > 1e-2).mean() < frac_1pc, (mb, float(np.median(rel)), float((rel > 1e-2).mean()))
         sg, so = p.r.stats(), p.o.counters()
         assert abs(int(sg.rays) - so["rays"]) <= 2e-3 * so["rays"] + 2, mb
