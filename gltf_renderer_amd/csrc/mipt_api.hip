@@ -53,7 +53,7 @@ struct pt_ctx {
     uint32_t* d_white = nullptr;                                   // 1x1 white texel behind every unbound material slot
     // interleaved albedo / normal / metal-rough texels of the materials whose three textures share one footprint (pt_types.h RM_TRIO),
     // keyed by the three texel pointers (nullptr = slot unbound); owned here, rebuilt / released by pt_scene_set_materials
-    struct TrioRec { const uint32_t *a, *n, *m; uint4* ptr; };
+    struct TrioRec { const uint32_t *a, *n, *m, *e; uint4* ptr; };
     std::vector<TrioRec> trios;
 
     // ---- per-frame arrays (Renderer::GatherMaterials / GatherLights)
@@ -678,9 +678,10 @@ int pt_sampler_create(pt_ctx* ctx, const pt_sampler_desc* d, int* handle_out) {
 }
 
 // {albedo, normal, metal-rough, -} per texel from the three RGBA8 images of one size (an unbound one reads as white, like d_white)
-__global__ void k_trio_interleave(uint4* __restrict__ dst, const uint32_t* __restrict__ a, const uint32_t* __restrict__ n, const uint32_t* __restrict__ m, size_t count) {
+__global__ void k_trio_interleave(uint4* __restrict__ dst, const uint32_t* __restrict__ a, const uint32_t* __restrict__ n, const uint32_t* __restrict__ m,
+                                  const uint32_t* __restrict__ e, size_t count) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) dst[i] = make_uint4(a[i], n ? n[i] : 0xffffffffu, m ? m[i] : 0xffffffffu, 0xffffffffu);
+    if (i < count) dst[i] = make_uint4(a[i], n ? n[i] : 0xffffffffu, m ? m[i] : 0xffffffffu, e ? e[i] : 0xffffffffu);
 }
 
 int pt_scene_set_materials(pt_ctx* ctx, const pt_material* m, int count) {
@@ -753,28 +754,33 @@ int pt_scene_set_materials(pt_ctx* ctx, const pt_material* m, int count) {
         const RTex& A = r.tex[SLOT_ALBEDO];
         const RTex& N = r.tex[SLOT_NORMAL];
         const RTex& M = r.tex[SLOT_METALLIC_ROUGHNESS];
+        const RTex& E = r.tex[SLOT_EMISSIVE];
         const bool ba = (r.bound_mask >> SLOT_ALBEDO) & 1u, bn = (r.bound_mask >> SLOT_NORMAL) & 1u, bm = (r.bound_mask >> SLOT_METALLIC_ROUGHNESS) & 1u;
         auto same_footprint = [&](const RTex& t) {
             return t.width == A.width && t.height == A.height && ((t.flags ^ A.flags) & ~(uint32_t)RT_SRGB) == 0 && memcmp(&t.m00, &A.m00, 6 * sizeof(float)) == 0;
         };
+        // the emissive texture joins when it has the footprint (it is fetched on its own otherwise); it does not make a copy worth building alone
+        const bool be = ((r.bound_mask >> SLOT_EMISSIVE) & 1u) && same_footprint(E);
         if (!ba || !(bn || bm) || (bn && !same_footprint(N)) || (bm && !same_footprint(M))) continue;
         const uint32_t* kn = bn ? N.texels : nullptr;
         const uint32_t* km = bm ? M.texels : nullptr;
+        const uint32_t* ke = be ? E.texels : nullptr;
         size_t at = ctx->trios.size();
         for (size_t k = 0; k < ctx->trios.size(); k++)
-            if (ctx->trios[k].a == A.texels && ctx->trios[k].n == kn && ctx->trios[k].m == km) { at = k; break; }
+            if (ctx->trios[k].a == A.texels && ctx->trios[k].n == kn && ctx->trios[k].m == km && ctx->trios[k].e == ke) { at = k; break; }
         if (at == ctx->trios.size()) {
             const size_t texels = (size_t)A.width * A.height;
             uint4* d = nullptr;
             if (hipMalloc((void**)&d, texels * 16 + 32) != hipSuccess) { (void)hipGetLastError(); continue; }     // no room: this material stays on the general path
-            hipLaunchKernelGGL(k_trio_interleave, dim3((unsigned)((texels + 255) / 256)), dim3(256), 0, ctx->stream, d, A.texels, kn, km, texels);
+            hipLaunchKernelGGL(k_trio_interleave, dim3((unsigned)((texels + 255) / 256)), dim3(256), 0, ctx->stream, d, A.texels, kn, km, ke, texels);
             HIPOK(hipMemsetAsync((char*)d + texels * 16, 0xff, 32, ctx->stream));
-            ctx->trios.push_back({A.texels, kn, km, d});
+            ctx->trios.push_back({A.texels, kn, km, ke, d});
             trio_live.push_back(0);
         }
         trio_live[at] = 1;
         r.trio = ctx->trios[at].ptr;
-        r.bound_mask |= RM_TRIO | ((bn && (N.flags & RT_SRGB)) ? RM_TRIO_SRGB_N : 0u) | ((bm && (M.flags & RT_SRGB)) ? RM_TRIO_SRGB_M : 0u);
+        r.bound_mask |= RM_TRIO | ((bn && (N.flags & RT_SRGB)) ? RM_TRIO_SRGB_N : 0u) | ((bm && (M.flags & RT_SRGB)) ? RM_TRIO_SRGB_M : 0u) |
+                        (be ? (RM_TRIO_EMISSIVE | ((E.flags & RT_SRGB) ? RM_TRIO_SRGB_E : 0u)) : 0u);
     }
     HIPOK(upload_table(ctx, ctx->d_rmats, ctx->rmats_cap, rm));
     ctx->rmats_host.swap(rm);
@@ -795,6 +801,12 @@ int pt_scene_set_materials(pt_ctx* ctx, const pt_material* m, int count) {
 extern "C" int pt_debug_interleaved_materials(const pt_ctx* ctx) {
     int n = 0;
     if (ctx) for (const RMat& r : ctx->rmats_host) n += (r.bound_mask & RM_TRIO) ? 1 : 0;
+    return n;
+}
+
+extern "C" int pt_debug_interleaved_emissive(const pt_ctx* ctx) {          // ... and how many of them carry their emissive texture in it
+    int n = 0;
+    if (ctx) for (const RMat& r : ctx->rmats_host) n += (r.bound_mask & RM_TRIO_EMISSIVE) ? 1 : 0;
     return n;
 }
 

@@ -389,6 +389,7 @@ struct Surface {                       // live subset of SurfaceProperties (Bsdf
     vec3 n, at, ab; float ior;
     vec3 spec_color; float spec_factor, clearcoat, cc_rough;
     vec3 cc_n, sheen_color; float sheen_a, transmissive;
+    vec3 emissive_texel;                                  // RM_TRIO_EMISSIVE materials: the filtered emissive texel, fetched with the PBR footprint
 };
 struct MatHeader {                     // the 128-B head of RMat in registers (8 x dwordx4 issued together)
     uint32_t flags; int32_t alpha_mode; float metalness_factor, roughness_factor;
@@ -463,8 +464,12 @@ PT_DEV vec3 normal_from_sample(vec4 s, float scale, vec3 gn, vec3 t, vec3 b) {  
     nm.x *= scale; nm.y *= scale;
     return normalize(to_world(t, b, gn, nm));
 }
-PT_DEV vec3 emissive_of(const SceneRec& sc, const RMat* m, const MatHeader& h, const vec2 tc[2], unsigned& taps) {   // :151-159
+// `fetched`: the filtered emissive texel when it came with the interleaved footprint (RM_TRIO_EMISSIVE, get_surface), else ignored
+PT_DEV vec3 emissive_of(const SceneRec& sc, const RMat* m, const MatHeader& h, const vec2 tc[2], unsigned& taps, vec3 fetched) {   // :151-159
     vec3 e = h.emissive_factor;
+#if PT_TEX_PAIRS && PT_TEX_TRIO
+    if (h.bound_mask & RM_TRIO_EMISSIVE) { taps++; return e * fetched; }
+#endif
     if (slot_bound(h.bound_mask, SLOT_EMISSIVE)) e = e * xyz(sample_slot(sc, m, SLOT_EMISSIVE, tc, taps));
     return e;
 }
@@ -476,6 +481,7 @@ PT_DEV vec3 normal_adaptation(vec3 ng, vec3 ns, vec3 v) {          // PathTracer
 }
 PT_DEV Surface get_surface(const SceneRec& sc, uint32_t flags, const RMat* m, const MatHeader& h, const HitGeom& a, vec3 view, unsigned& taps) {
     Surface s;
+    s.emissive_texel = v3(0);
     // The three usual PBR textures are fetched as ONE batch: their slot records are loaded together, their twelve texel
     // gathers are issued together (unbound slots read a 1x1 white texel, so there is no branch to split the batch).
     const uint32_t mid = (uint32_t)(m - sc.rmats);
@@ -502,6 +508,11 @@ PT_DEV Surface get_surface(const SceneRec& sc, uint32_t flags, const RMat* m, co
             a00 = t00.x; a10 = t10.x; a01 = t01.x; a11 = t11.x;
             n00 = t00.y; n10 = t10.y; n01 = t01.y; n11 = t11.y;
             m00 = t00.z; m10 = t10.z; m01 = t01.z; m11 = t11.z;
+            if (h.bound_mask & RM_TRIO_EMISSIVE) {
+                TexTaps k_em = k_alb;
+                k_em.srgb = (h.bound_mask & RM_TRIO_SRGB_E) ? (uint32_t)RT_SRGB : 0u;
+                s.emissive_texel = xyz(resolve_taps(k_em, t00.w, t10.w, t01.w, t11.w, sc.srgb_lut));
+            }
         }
     }
     if (__any(!trio)) {

@@ -59,9 +59,11 @@ static_assert(sizeof(RTex) == 48, "RTex");
 enum { RT_SRGB = 1, RT_POINT = 32, RT_TEXCOORD1 = 64 };
 // bound_mask bits beyond the 15 slots.  RM_TRIO: the albedo slot is bound and the bound ones of the normal and metal-rough slots share
 // its image size, sampler state, UV set and UV transform, so the three bilinear footprints are the SAME four texels and `trio` holds
-// them side by side: {albedo, normal, metal-rough, -} per texel.  One footprint then costs two 32-B pieces instead of six 8-B pieces in
+// them side by side: {albedo, normal, metal-rough, emissive} per texel.  One footprint then costs two 32-B pieces instead of six 8-B pieces in
 // six different cache lines (a hit's texel fetches were 6 of its ~13 HBM lines).  RM_TRIO_SRGB_N / _M: sRGB flag of the other two.
-enum : uint32_t { RM_TRIO = 1u << 16, RM_TRIO_SRGB_N = 1u << 17, RM_TRIO_SRGB_M = 1u << 18 };
+// RM_TRIO_EMISSIVE: the emissive texture has that footprint too and rides in the copy's fourth component (RM_TRIO_SRGB_E its sRGB flag):
+// the one texture fetch a hit made after the batch -- a dependent round trip and two more cache lines -- comes with it.
+enum : uint32_t { RM_TRIO = 1u << 16, RM_TRIO_SRGB_N = 1u << 17, RM_TRIO_SRGB_M = 1u << 18, RM_TRIO_EMISSIVE = 1u << 19, RM_TRIO_SRGB_E = 1u << 20 };
 enum { SLOT_NORMAL = 0, SLOT_ALBEDO, SLOT_METALLIC_ROUGHNESS, SLOT_OCCLUSION, SLOT_EMISSIVE, SLOT_SPECULAR, SLOT_SPECULAR_COLOR, SLOT_CLEARCOAT,
        SLOT_CLEARCOAT_ROUGHNESS, SLOT_CLEARCOAT_NORMAL, SLOT_ANISOTROPY, SLOT_SHEEN_COLOR, SLOT_SHEEN_ROUGHNESS, SLOT_TRANSMISSION, SLOT_THICKNESS,
        SLOT_COUNT };

@@ -117,7 +117,7 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
         return true;
     }
     const Lobes lobes = lobe_probabilities(sp, view);
-    vec3 c = emissive_of(sc, mat, mh, va.tc, taps);                                                     // :925-926
+    vec3 c = emissive_of(sc, mat, mh, va.tc, taps, sp.emissive_texel);                                                     // :925-926
     fu.origin_above = o_above;
     PT_TICK(2)
     // environment NEE :929-942 (SampleEnvironmentMap :688-703)

@@ -661,6 +661,8 @@ def interleave_scene(size=160):
     b64, mr64, nm64 = tex_set(64)
     b32, mr32, nm32 = tex_set(32)
     b1, mr1, nm1 = tex_set(16, 1)                       # 1 texel wide, 16 high
+    em64 = s.add_texture(scenes.rgba(scenes.value_noise(rng, 64, 3, 2) ** 3, 0.5 * scenes.value_noise(rng, 64, 3, 2) ** 2, 0.2 * scenes.value_noise(rng, 64, 2, 2)), True)
+    em32 = s.add_texture(scenes.rgba(scenes.value_noise(rng, 32, 3, 2) ** 2, scenes.value_noise(rng, 32, 3, 2) ** 3, 0.1 * scenes.value_noise(rng, 32, 2, 2)), False)
     smp_mc = s.add_sampler(abi.ADDRESS_MIRROR, abi.ADDRESS_CLAMP, abi.FILTER_LINEAR, abi.FILTER_LINEAR)
     smp_pt = s.add_sampler(abi.ADDRESS_WRAP, abi.ADDRESS_WRAP, abi.FILTER_POINT, abi.FILTER_POINT)
     tile = dict(rotation=0.4, offset=(0.13, 0.27), scale=(3.0, 2.0))
@@ -680,21 +682,25 @@ def interleave_scene(size=160):
         M(albedo=TS(b64), metallic_roughness=TS(mr64), normal=TS(nm64, 0, 1)),                                       # general: UV set differs
         M(normal=TS(nm64), metallic_roughness=TS(mr64)),                                                             # general: no albedo texture
         M(albedo=TS(b64)),                                                                                           # general: albedo only
+        M(albedo=TS(b64), metallic_roughness=TS(mr64), normal=TS(nm64), emissive=TS(em64), emissive_factor=(1.5, 1.2, 2.0)),   # interleaved, emissive rides along (sRGB)
+        M(albedo=TS(b32, 0, 0, **tile), metallic_roughness=TS(mr32, 0, 0, **tile), emissive=TS(em32, 0, 0, **tile), emissive_factor=(2.0, 2.0, 2.0)),   # same, linear, tiled
+        M(albedo=TS(b64), normal=TS(nm64), emissive=TS(em32), emissive_factor=(1.0, 2.0, 1.0)),                       # interleaved; emissive of another size fetched on its own
+        M(albedo=TS(b64), emissive=TS(em64), emissive_factor=(1.0, 1.0, 1.0)),                                       # general: an emissive texture alone does not make a copy
     ]
     ids = [s.add_material(m) for m in mats]
     cols = 5
     for k, mid in enumerate(ids):
-        cx, cz = (k % cols - (cols - 1) / 2) * 1.05, (k // cols - 1) * 1.05
+        cx, cz = (k % cols - (cols - 1) / 2) * 1.05, (k // cols - 1.5) * 1.05
         g = meshgen.grid(6, 6, (cx - 0.5, 0.0, cz - 0.5), (1, 0, 0), (0, 0, 1), (1, 1))
         g.uv1 = (g.uv0 * f32(1.7) + f32(0.2)).astype(f32)
         s.add_mesh(g, None, mid)
     s.add_light(abi.LIGHT_POINT, position=(0.5, -2.0, 0.3), color=(1, 0.9, 0.8), intensity=30.0)
     s.add_light(abi.LIGHT_DIRECTIONAL, direction=(0.2, 1.0, -0.3), color=(1, 1, 1), intensity=2.0)
-    s.world_to_view = camera.orbit_world_to_view((0, 0, 0), 3.2, 0.0, 0.0)
+    s.world_to_view = camera.orbit_world_to_view((0, 0, 0), 3.6, 0.0, 0.0)
     s.width, s.height = size, size * 3 // 4
     s.settings.max_bounces = 3
     s.settings.flags &= ~abi.FLAG_ENVIRONMENT_MAP
-    return s, 7
+    return s, 10, 2
 
 
 @pytest.mark.parametrize("mode", ["wavefront", "megakernel"])
@@ -702,7 +708,7 @@ def test_interleaved_texel_footprint_is_bit_identical_to_the_general_path(R, ora
     """pt_scene_set_materials interleaves the albedo / normal / metal-rough texels of the materials whose three footprints coincide;
     the shade stage then reads two 32-B pieces a row pair instead of six 8-B pieces.  Same texels, same weights: the image must not
     change by one bit, whatever mix of materials a wave holds, and must match the oracle (which knows nothing of it)."""
-    s, expect_interleaved = interleave_scene()
+    s, expect_interleaved, expect_emissive = interleave_scene()
     frames = 6
     def render(env):
         if env is None: monkeypatch.delenv("MIPT_TEXTURE_INTERLEAVE", raising=False)
@@ -710,7 +716,7 @@ def test_interleaved_texel_footprint_is_bit_identical_to_the_general_path(R, ora
         r = R()
         if mode == "megakernel": r.set_kernel_mode(1)
         h = s.upload(r)
-        n = r.L.pt_debug_interleaved_materials(r.h)
+        n = (r.L.pt_debug_interleaved_materials(r.h), r.L.pt_debug_interleaved_emissive(r.h))
         out = r.create_output(s.width, s.height)
         for f in range(frames):
             r.trace(s.settings, s.execute_params(frame=f), out)
@@ -719,7 +725,7 @@ def test_interleaved_texel_footprint_is_bit_identical_to_the_general_path(R, ora
         return img, n
     a, na = render(None)
     b, nb = render("0")
-    assert na == expect_interleaved and nb == 0, (na, nb)
+    assert na == (expect_interleaved, expect_emissive) and nb == (0, 0), (na, nb)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "interleaved footprint changed %d pixels" % int((a != b).any(axis=2).sum())
     o = oracle_lib.Oracle()
     s.upload(o)
@@ -732,7 +738,7 @@ def test_interleaved_texel_footprint_is_bit_identical_to_the_general_path(R, ora
 
 def test_interleaved_copies_follow_the_material_table(R):
     """A new material table releases the copies it no longer names and reuses the ones it does; textures stay destroyable."""
-    s, n = interleave_scene(64)
+    s, n, _ = interleave_scene(64)
     r = R()
     h = s.upload(r)
     assert r.L.pt_debug_interleaved_materials(r.h) == n
