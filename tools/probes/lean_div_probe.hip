@@ -5,19 +5,13 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include "../../gltf_renderer_amd/csrc/pt_math.h"      // pt::fdiv, pt::hpow: the library's own functions are what is checked
 __device__ __forceinline__ uint32_t pcg(uint32_t& s) { s = s * 747796405u + 2891336453u; uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u; return (w >> 22u) ^ w; }
 __device__ __forceinline__ float rnd_float(uint32_t& s, int emin, int emax) {          // random sign, exponent in [emin, emax], random mantissa
     const uint32_t m = pcg(s) & 0x7fffffu, e = (uint32_t)(127 + emin) + pcg(s) % (uint32_t)(emax - emin + 1), sg = pcg(s) & 0x80000000u;
     return __uint_as_float(sg | (e << 23) | m);
 }
-__device__ __forceinline__ float div_l1(float a, float b) {
-    float r = __builtin_amdgcn_rcpf(b);
-    const float e = __builtin_fmaf(-b, r, 1.0f);
-    r = __builtin_fmaf(e, r, r);
-    float q = a * r;
-    const float m = __builtin_fmaf(-b, q, a);
-    return __builtin_fmaf(m, r, q);
-}
+__device__ __forceinline__ float div_l1(float a, float b) { return pt::fdiv(a, b); }     // L1 = pt_math.h's fdiv
 __device__ __forceinline__ float div_l2(float a, float b) {
     float r = __builtin_amdgcn_rcpf(b);
     const float e = __builtin_fmaf(-b, r, 1.0f);
