@@ -727,10 +727,18 @@ PT_DEV vec3 gltf_bsdf(const float* lut, const Surface& s, vec3 v, vec3 l, int mo
 // ---------------------------------------------------------------- sampling (Sampling.hlsli, Transforms.hlsli)
 PT_DEV vec2 uv_to_square(vec2 uv) { return {uv.x * 2 + -1, uv.y * -2 + 1}; }                                   // Transforms.hlsli:52-55
 PT_DEV vec2 square_to_uv(vec2 s) { return {(s.x - -1) * 0.5f, (s.y - 1) * -0.5f}; }                            // :57-60
+// Each direction sampler is split into the angle it takes the sine and cosine of and the rest: sample_bsdf's lobes diverge inside a wave
+// (half the lanes sample the cosine lobe, half the specular one), and ONE sinf / cosf pair of a per-lane angle serves every lobe -- the two
+// ~125-instruction calls used to run once per lobe present in the wave, each with part of the lanes.  Same arguments, same bits.
+PT_DEV float square_to_disk_angle(vec2 s, float& r) {
+    r = hmax(fabsf(s.x), fabsf(s.y));
+    return r == 0 ? 0 : fdiv(kPi * (r + (fabsf(s.y) - fabsf(s.x))), 4 * r);
+}
+PT_DEV vec2 square_to_disk_finish(vec2 s, float r, float cs, float sn) { return {signf(s.x) * r * cs, signf(s.y) * r * sn}; }
 PT_DEV vec2 square_to_disk(vec2 s) {                                                                           // :83-90
-    float r = hmax(fabsf(s.x), fabsf(s.y));
-    float phi = r == 0 ? 0 : fdiv(kPi * (r + (fabsf(s.y) - fabsf(s.x))), 4 * r);
-    return {signf(s.x) * r * cosf(phi), signf(s.y) * r * sinf(phi)};
+    float r;
+    const float phi = square_to_disk_angle(s, r);
+    return square_to_disk_finish(s, r, cosf(phi), sinf(phi));
 }
 PT_DEV vec3 square_to_sphere(vec2 s) {                                                                         // :124-136
     float d = 1 - (fabsf(s.x) + fabsf(s.y));
@@ -759,18 +767,24 @@ PT_DEV vec3 cubemap_to_direction(int face, float u, float v) {                  
     u = u * 2 - 1; v = v * 2 - 1;
     return normalize(fd + u * ud + v * vd);
 }
-PT_DEV vec3 sample_cosine_hemisphere(vec3 n, float u0, float u1) {                                             // Sampling.hlsli:26-33
-    float theta = kTau * u0;
+PT_DEV vec3 sample_cosine_hemisphere_finish(vec3 n, float u1, float cs, float sn) {       // cs, sn = cos, sin of kTau * u0
     float y = 2 * u1 - 1;
     float s = sqrtf(1.0f - y * y);
-    return normalize(n + v3(s * cosf(theta), s * sinf(theta), y));
+    return normalize(n + v3(s * cs, s * sn, y));
+}
+PT_DEV vec3 sample_cosine_hemisphere(vec3 n, float u0, float u1) {                                             // Sampling.hlsli:26-33
+    float theta = kTau * u0;
+    return sample_cosine_hemisphere_finish(n, u1, cosf(theta), sinf(theta));
 }
 PT_DEV float cosine_hemisphere_pdf(vec3 n, vec3 v) { return saturate(fdiv(dot(v, n), kPi)); }                       // :35-38
-PT_DEV vec3 sample_ggx_normal(float a, float u0, float u1) {                                                   // :41-52
-    float phi = kTau * u0;
+PT_DEV vec3 sample_ggx_normal_finish(float a, float u1, float cs, float sn) {              // cs, sn = cos, sin of kTau * u0
     float ct = sqrtf(fdiv(1 - u1, 1 + (a * a - 1) * u1));
     float st = sqrtf(1 - ct * ct);
-    return {st * cosf(phi), st * sinf(phi), ct};
+    return {st * cs, st * sn, ct};
+}
+PT_DEV vec3 sample_ggx_normal(float a, float u0, float u1) {                                                   // :41-52
+    float phi = kTau * u0;
+    return sample_ggx_normal_finish(a, u1, cosf(phi), sinf(phi));
 }
 PT_DEV float ggx_normal_pdf(float a, vec3 n, vec3 h) { float ndh = dot(n, h); return ggx_d(a, ndh) * ndh; }    // :54-58
 
@@ -861,9 +875,15 @@ PT_DEV vec3 sample_bsdf(uint32_t flags, const float* lut, const Surface& s, cons
             l = -v; use_mis = false; pdf = p.alpha; is_transmission = true;
             return v3(1 - s.alpha);
         }
-        if (layer == 0 || layer == 2) l = sample_cosine_hemisphere(s.n, u.y, u.z);          // diffuse :462-465, sheen :418-421
+        // the angle each lobe's sampler takes the sine and cosine of, then one sinf / cosf pair for the whole wave (see square_to_disk_angle)
+        const vec2 sq = uv_to_square({u.y, u.z});
+        float disk_r = 0;
+        const float disk_phi = square_to_disk_angle(sq, disk_r);
+        const float angle = layer == 1 ? disk_phi : kTau * u.y;
+        const float cs = cosf(angle), sn = sinf(angle);
+        if (layer == 0 || layer == 2) l = sample_cosine_hemisphere_finish(s.n, u.z, cs, sn);  // diffuse :462-465, sheen :418-421
         else if (layer == 1) {                              // SampleSpecular :428-442, SampleGgxAnisotropicNormal Sampling.hlsli:60-65
-            vec2 d = square_to_disk(uv_to_square({u.y, u.z}));
+            vec2 d = square_to_disk_finish(sq, disk_r, cs, sn);
             vec3 hl = v3(d.x, d.y, sqrtf(1 - d.x * d.x - d.y * d.y));
             hl.x *= s.ax; hl.y *= s.ay;
             hl = normalize(hl);
@@ -871,10 +891,10 @@ PT_DEV vec3 sample_bsdf(uint32_t flags, const float* lut, const Surface& s, cons
         } else if (layer == 3) {                            // SampleClearcoat :394-406
             vec3 t, b;
             basis_simple(s.cc_n, t, b);
-            l = reflect(-v, to_world(t, b, s.cc_n, sample_ggx_normal(s.cc_rough, u.y, u.z)));
+            l = reflect(-v, to_world(t, b, s.cc_n, sample_ggx_normal_finish(s.cc_rough, u.z, cs, sn)));
         } else {                                            // SampleTransmission :472-487
             float a = modulate_roughness(s.ay, s.ior);
-            vec3 h = to_world(s.at, s.ab, s.n, sample_ggx_normal(a, u.y, u.z));
+            vec3 h = to_world(s.at, s.ab, s.n, sample_ggx_normal_finish(a, u.z, cs, sn));
             l = reflect(-v, h);
             l = l - 2 * dot(s.n, l) * s.n;
             is_transmission = true;
