@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void k_equirect_to_cube(const float* __restric
     if (x >= n) return;
     float u = ((float)x + .5f) / (float)n, v = ((float)y + .5f) / (float)n;                   // PixelToUV
     vec3 d = cubemap_to_direction(face, u, v);
-    float eu = atan2f(d.y, d.x) / 6.28318530717f, ev = 1 - ((d.z + 1) / 2);                   // equal-area in z (quirk q8)
+    float eu = pt_atan2(d.y, d.x) / 6.28318530717f, ev = 1 - ((d.z + 1) / 2);                   // equal-area in z (quirk q8)
     vec3 c = equirect_bilinear(img, w, h, eu, ev);
     __half hx = __float2half_rn(c.x), hy = __float2half_rn(c.y), hz = __float2half_rn(c.z), hw = __float2half_rn(1.0f);
     uint2 q = make_uint2((uint32_t)__half_as_ushort(hx) | ((uint32_t)__half_as_ushort(hy) << 16),

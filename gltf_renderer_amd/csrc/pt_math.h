@@ -120,6 +120,30 @@ PT_DEV float lerpf(float a, float b, float t) { return a + t * (b - a); }
 PT_DEV vec3 lerp3(vec3 a, vec3 b, float t) { return a + t * (b - a); }
 PT_DEV float signf(float x) { return x > 0 ? 1.0f : (x < 0 ? -1.0f : 0.0f); }
 PT_DEV vec3 reflect(vec3 i, vec3 n) { return i - 2 * dot(n, i) * n; }
+// sin and cos are evaluated in DOUBLE precision and rounded once: the correctly rounded fp32 value in all but one case in ~1e9, which is
+// what the CPU oracle's libm returns.  The device library's fp32 sinf / cosf are within 1-2 ulp of that -- and on the Sponza-class scene
+// those last bits, in the directions the BSDF samplers and the environment sampler draw, were ALL that still made 0.04 % of the
+// pixel-samples take another path than the oracle's: with them the scene measures 8.4e-4 at 64 spp (4.9e-3 without) and no pixel-sample
+// beyond 1e-2.  Costs ~1 % of the frame rate (a few calls per hit; MI355X runs fp64 at half the fp32 rate).  atan2 and exp feed continuous
+// quantities only (a pdf on a miss, the sheen visibility): their fp32 library versions leave every parity figure where it is, their
+// double versions cost another 0.5 %, so they stay fp32; pow through double costs 17 % and changes nothing.
+// PT_F64_TRANSCENDENTALS=0: the fp32 library sinf / cosf (A/B).
+#ifndef PT_F64_TRANSCENDENTALS
+#define PT_F64_TRANSCENDENTALS 1
+#endif
+#if PT_F64_TRANSCENDENTALS
+PT_DEV float pt_sin(float x) { return (float)sin((double)x); }
+PT_DEV float pt_cos(float x) { return (float)cos((double)x); }
+#else
+PT_DEV float pt_sin(float x) { return sinf(x); }
+PT_DEV float pt_cos(float x) { return cosf(x); }
+#endif
+PT_DEV float pt_atan2(float y, float x) { return atan2f(y, x); }
+PT_DEV float pt_exp(float x) { return expf(x); }
+// PT_F64_POW=1 (experiment): pow's log2 and exp2 through double as well
+#ifndef PT_F64_POW
+#define PT_F64_POW 0
+#endif
 // pow(x, y) = exp2(y * log2 x).  The library's exp2f / log2f are v_exp_f32 / v_log_f32 wrapped in range scaling for
 // subnormal arguments and results (9 + 8 instructions); the bare instructions give the same bits everywhere else and flush those to
 // zero -- Schlick's (1 - c)^5 below 2^-126.  PT_LIBM_POW=1 keeps the library calls (A/B, tools/compare_builds.py).
@@ -128,6 +152,8 @@ PT_DEV vec3 reflect(vec3 i, vec3 n) { return i - 2 * dot(n, i) * n; }
 #endif
 #if PT_LIBM_POW
 PT_DEV float hpow(float x, float y) { return exp2f(y * log2f(x)); }
+#elif PT_F64_POW
+PT_DEV float hpow(float x, float y) { return (float)exp2((double)(y * (float)log2((double)x))); }
 #else
 PT_DEV float hpow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
 #endif

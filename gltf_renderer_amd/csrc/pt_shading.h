@@ -61,7 +61,7 @@ PT_DEV void basis_simple(vec3 n, vec3& t, vec3& b) {               // Common.hls
 // transcendentals per vertex fewer in the shade stage.
 PT_DEV float2 tangent_sincos_compute(uint32_t k) {
     const float angle = kTau * unorm_div<1023>((float)k);
-    return make_float2(sinf(angle), cosf(angle));
+    return make_float2(pt_sin(angle), pt_cos(angle));
 }
 PT_DEV void decode_tangent_space(uint32_t p, float2 sincos, vec3& normal, vec3& tangent, float& winding) {
     float ex = unorm_div<1023>((float)(p & 0x3ff)), ey = unorm_div<1023>((float)((p >> 10) & 0x3ff));
@@ -80,7 +80,7 @@ PT_DEV uint32_t encode_tangent_space(vec3 normal, vec3 tangent, float winding) {
     vec3 nq = decode_octahedral(2.0f * unorm_div<1023>((float)qx) - 1.0f, 2.0f * unorm_div<1023>((float)qy) - 1.0f);
     vec3 ct, cb;
     basis_accurate(nq, ct, cb);
-    float angle = atan2f(dot(tangent, cb), dot(tangent, ct));
+    float angle = pt_atan2(dot(tangent, cb), dot(tangent, ct));
     uint32_t qt = f2u((fdiv(angle, kTau) + 0.5f) * 1023 + 0.5f);
     uint32_t qw = winding == 1 ? 3u : 0u;
     return qx | (qy << 10) | (qt << 20) | (qw << 30);
@@ -647,8 +647,8 @@ PT_DEV float sheen_l(float alpha, float x) {                                    
     return fdiv(a, 1 + b * hpow(x, c)) + d * x + e;
 }
 PT_DEV float sheen_shadowing(float alpha, float c) {                                                           // :186-193
-    if (c < 0.5f) return expf(sheen_l(alpha, c));
-    return expf(2 * sheen_l(alpha, 0.5f) - sheen_l(alpha, 1 - c));
+    if (c < 0.5f) return pt_exp(sheen_l(alpha, c));
+    return pt_exp(2 * sheen_l(alpha, 0.5f) - sheen_l(alpha, 1 - c));
 }
 PT_DEV float sheen_brdf(float alpha, float ndl, float ndv, float ndh) {                                        // :166-173,195-203
     float inv_r = fdiv(1.0f, alpha);
@@ -738,18 +738,18 @@ PT_DEV vec2 square_to_disk_finish(vec2 s, float r, float cs, float sn) { return 
 PT_DEV vec2 square_to_disk(vec2 s) {                                                                           // :83-90
     float r;
     const float phi = square_to_disk_angle(s, r);
-    return square_to_disk_finish(s, r, cosf(phi), sinf(phi));
+    return square_to_disk_finish(s, r, pt_cos(phi), pt_sin(phi));
 }
 PT_DEV vec3 square_to_sphere(vec2 s) {                                                                         // :124-136
     float d = 1 - (fabsf(s.x) + fabsf(s.y));
     float r = 1 - fabsf(d);
     float phi = (r == 0) ? 0 : (kPi / 4) * (fdiv(fabsf(s.y) - fabsf(s.x), r) + 1);
     float f = r * sqrtf(2 - r * r);
-    return {f * signf(s.x) * cosf(phi), f * signf(s.y) * sinf(phi), signf(d) * (1 - r * r)};
+    return {f * signf(s.x) * pt_cos(phi), f * signf(s.y) * pt_sin(phi), signf(d) * (1 - r * r)};
 }
 PT_DEV vec2 sphere_to_square(vec3 p) {                                                                         // :138-149
     float r = sqrtf(1 - fabsf(p.z));
-    float phi = atan2f(fabsf(p.y), fabsf(p.x));
+    float phi = pt_atan2(fabsf(p.y), fabsf(p.x));
     float d = signf(p.z) * (1 - r);
     float diff = r * ((4 / kPi) * phi - 1);
     return {signf(p.x) * 0.5f * (1 - d - diff), signf(p.y) * 0.5f * (1 - d + diff)};
@@ -774,7 +774,7 @@ PT_DEV vec3 sample_cosine_hemisphere_finish(vec3 n, float u1, float cs, float sn
 }
 PT_DEV vec3 sample_cosine_hemisphere(vec3 n, float u0, float u1) {                                             // Sampling.hlsli:26-33
     float theta = kTau * u0;
-    return sample_cosine_hemisphere_finish(n, u1, cosf(theta), sinf(theta));
+    return sample_cosine_hemisphere_finish(n, u1, pt_cos(theta), pt_sin(theta));
 }
 PT_DEV float cosine_hemisphere_pdf(vec3 n, vec3 v) { return saturate(fdiv(dot(v, n), kPi)); }                       // :35-38
 PT_DEV vec3 sample_ggx_normal_finish(float a, float u1, float cs, float sn) {              // cs, sn = cos, sin of kTau * u0
@@ -784,7 +784,7 @@ PT_DEV vec3 sample_ggx_normal_finish(float a, float u1, float cs, float sn) {   
 }
 PT_DEV vec3 sample_ggx_normal(float a, float u0, float u1) {                                                   // :41-52
     float phi = kTau * u0;
-    return sample_ggx_normal_finish(a, u1, cosf(phi), sinf(phi));
+    return sample_ggx_normal_finish(a, u1, pt_cos(phi), pt_sin(phi));
 }
 PT_DEV float ggx_normal_pdf(float a, vec3 n, vec3 h) { float ndh = dot(n, h); return ggx_d(a, ndh) * ndh; }    // :54-58
 
@@ -880,7 +880,7 @@ PT_DEV vec3 sample_bsdf(uint32_t flags, const float* lut, const Surface& s, cons
         float disk_r = 0;
         const float disk_phi = square_to_disk_angle(sq, disk_r);
         const float angle = layer == 1 ? disk_phi : kTau * u.y;
-        const float cs = cosf(angle), sn = sinf(angle);
+        const float cs = pt_cos(angle), sn = pt_sin(angle);
         if (layer == 0 || layer == 2) l = sample_cosine_hemisphere_finish(s.n, u.z, cs, sn);  // diffuse :462-465, sheen :418-421
         else if (layer == 1) {                              // SampleSpecular :428-442, SampleGgxAnisotropicNormal Sampling.hlsli:60-65
             vec2 d = square_to_disk_finish(sq, disk_r, cs, sn);
@@ -923,8 +923,8 @@ static __shared__ float4 pt_lds_light[kLightCacheMax * 4];
 // staged light, by the expressions light_ray() uses, and kept in the record's two padding floats of the LDS copy: every wave holds a
 // lane that picked the spot light, so every hit used to pay for them.
 PT_DEV void spot_cone_terms(float inner_angle, float outer_angle, float& scale, float& offset) {
-    scale = fdiv(1.0f, hmax(0.001f, cosf(inner_angle) - cosf(outer_angle)));
-    offset = -cosf(outer_angle) * scale;
+    scale = fdiv(1.0f, hmax(0.001f, pt_cos(inner_angle) - pt_cos(outer_angle)));
+    offset = -pt_cos(outer_angle) * scale;
 }
 PT_DEV void stage_lights(const SceneRec& sc, int num_of_lights) {   // 256-thread workgroups
     const uint32_t n = (uint32_t)(num_of_lights < kLightCacheMax ? num_of_lights : kLightCacheMax), n4 = n * 4u;
@@ -951,8 +951,8 @@ PT_DEV pt_light load_light(const SceneRec& sc, uint32_t li, bool& cone_terms_sta
 }
 #else
 PT_DEV void spot_cone_terms(float inner_angle, float outer_angle, float& scale, float& offset) {
-    scale = fdiv(1.0f, hmax(0.001f, cosf(inner_angle) - cosf(outer_angle)));
-    offset = -cosf(outer_angle) * scale;
+    scale = fdiv(1.0f, hmax(0.001f, pt_cos(inner_angle) - pt_cos(outer_angle)));
+    offset = -pt_cos(outer_angle) * scale;
 }
 PT_DEV void stage_lights(const SceneRec&, int) {}
 PT_DEV pt_light load_light(const SceneRec& sc, uint32_t li, bool& cone_terms_staged) { cone_terms_staged = false; return sc.lights[li]; }
