@@ -138,6 +138,19 @@ PT_DEV float pt_cos(float x) { return (float)cos((double)x); }
 PT_DEV float pt_sin(float x) { return sinf(x); }
 PT_DEV float pt_cos(float x) { return cosf(x); }
 #endif
+// both of one angle: one argument reduction in double for the pair (PT_SINCOS_PAIR=0: two separate calls, for A/B)
+#ifndef PT_SINCOS_PAIR
+#define PT_SINCOS_PAIR 1
+#endif
+PT_DEV void pt_sincos(float x, float& s, float& c) {
+#if PT_F64_TRANSCENDENTALS && PT_SINCOS_PAIR
+    double ds, dc;
+    sincos((double)x, &ds, &dc);
+    s = (float)ds; c = (float)dc;
+#else
+    s = pt_sin(x); c = pt_cos(x);
+#endif
+}
 PT_DEV float pt_atan2(float y, float x) { return atan2f(y, x); }
 PT_DEV float pt_exp(float x) { return expf(x); }
 // PT_F64_POW=1 (experiment): pow's log2 and exp2 through double as well

@@ -61,7 +61,9 @@ PT_DEV void basis_simple(vec3 n, vec3& t, vec3& b) {               // Common.hls
 // transcendentals per vertex fewer in the shade stage.
 PT_DEV float2 tangent_sincos_compute(uint32_t k) {
     const float angle = kTau * unorm_div<1023>((float)k);
-    return make_float2(pt_sin(angle), pt_cos(angle));
+    float sn_, cs_;
+    pt_sincos(angle, sn_, cs_);
+    return make_float2(sn_, cs_);
 }
 PT_DEV void decode_tangent_space(uint32_t p, float2 sincos, vec3& normal, vec3& tangent, float& winding) {
     float ex = unorm_div<1023>((float)(p & 0x3ff)), ey = unorm_div<1023>((float)((p >> 10) & 0x3ff));
@@ -738,14 +740,18 @@ PT_DEV vec2 square_to_disk_finish(vec2 s, float r, float cs, float sn) { return 
 PT_DEV vec2 square_to_disk(vec2 s) {                                                                           // :83-90
     float r;
     const float phi = square_to_disk_angle(s, r);
-    return square_to_disk_finish(s, r, pt_cos(phi), pt_sin(phi));
+    float sn_, cs_;
+    pt_sincos(phi, sn_, cs_);
+    return square_to_disk_finish(s, r, cs_, sn_);
 }
 PT_DEV vec3 square_to_sphere(vec2 s) {                                                                         // :124-136
     float d = 1 - (fabsf(s.x) + fabsf(s.y));
     float r = 1 - fabsf(d);
     float phi = (r == 0) ? 0 : (kPi / 4) * (fdiv(fabsf(s.y) - fabsf(s.x), r) + 1);
     float f = r * sqrtf(2 - r * r);
-    return {f * signf(s.x) * pt_cos(phi), f * signf(s.y) * pt_sin(phi), signf(d) * (1 - r * r)};
+    float sn_, cs_;
+    pt_sincos(phi, sn_, cs_);
+    return {f * signf(s.x) * cs_, f * signf(s.y) * sn_, signf(d) * (1 - r * r)};
 }
 PT_DEV vec2 sphere_to_square(vec3 p) {                                                                         // :138-149
     float r = sqrtf(1 - fabsf(p.z));
@@ -774,7 +780,9 @@ PT_DEV vec3 sample_cosine_hemisphere_finish(vec3 n, float u1, float cs, float sn
 }
 PT_DEV vec3 sample_cosine_hemisphere(vec3 n, float u0, float u1) {                                             // Sampling.hlsli:26-33
     float theta = kTau * u0;
-    return sample_cosine_hemisphere_finish(n, u1, pt_cos(theta), pt_sin(theta));
+    float sn_, cs_;
+    pt_sincos(theta, sn_, cs_);
+    return sample_cosine_hemisphere_finish(n, u1, cs_, sn_);
 }
 PT_DEV float cosine_hemisphere_pdf(vec3 n, vec3 v) { return saturate(fdiv(dot(v, n), kPi)); }                       // :35-38
 PT_DEV vec3 sample_ggx_normal_finish(float a, float u1, float cs, float sn) {              // cs, sn = cos, sin of kTau * u0
@@ -784,7 +792,9 @@ PT_DEV vec3 sample_ggx_normal_finish(float a, float u1, float cs, float sn) {   
 }
 PT_DEV vec3 sample_ggx_normal(float a, float u0, float u1) {                                                   // :41-52
     float phi = kTau * u0;
-    return sample_ggx_normal_finish(a, u1, pt_cos(phi), pt_sin(phi));
+    float sn_, cs_;
+    pt_sincos(phi, sn_, cs_);
+    return sample_ggx_normal_finish(a, u1, cs_, sn_);
 }
 PT_DEV float ggx_normal_pdf(float a, vec3 n, vec3 h) { float ndh = dot(n, h); return ggx_d(a, ndh) * ndh; }    // :54-58
 
@@ -880,7 +890,8 @@ PT_DEV vec3 sample_bsdf(uint32_t flags, const float* lut, const Surface& s, cons
         float disk_r = 0;
         const float disk_phi = square_to_disk_angle(sq, disk_r);
         const float angle = layer == 1 ? disk_phi : kTau * u.y;
-        const float cs = pt_cos(angle), sn = pt_sin(angle);
+        float cs, sn;
+        pt_sincos(angle, sn, cs);
         if (layer == 0 || layer == 2) l = sample_cosine_hemisphere_finish(s.n, u.z, cs, sn);  // diffuse :462-465, sheen :418-421
         else if (layer == 1) {                              // SampleSpecular :428-442, SampleGgxAnisotropicNormal Sampling.hlsli:60-65
             vec2 d = square_to_disk_finish(sq, disk_r, cs, sn);
