@@ -716,7 +716,7 @@ int pt_scene_set_materials(pt_ctx* ctx, const pt_material* m, int count) {
         r.ior = s.ior; r.normal_scale = s.normal_scale; r.specular_factor = s.specular_factor; r.clearcoat_normal_scale = s.clearcoat_normal_scale;
         memcpy(r.specular_color_factor, s.specular_color_factor, 12); r.clearcoat_factor = s.clearcoat_factor;
         r.clearcoat_roughness_factor = s.clearcoat_roughness_factor; r.anisotropy_strength = s.anisotropy_strength;
-        r.anisotropy_cos = cosf(s.anisotropy_rotation); r.anisotropy_sin = sinf(s.anisotropy_rotation);
+        r.anisotropy_cos = (float)cos((double)s.anisotropy_rotation); r.anisotropy_sin = (float)sin((double)s.anisotropy_rotation);   // correctly rounded, like the kernels' (pt_math.h pt_sincos)
         memcpy(r.sheen_color_factor, s.sheen_color_factor, 12); r.sheen_roughness_factor = s.sheen_roughness_factor;
         r.transmission_factor = s.transmission_factor;
         const pt_texture_sample* slots[SLOT_COUNT] = {&s.normal, &s.albedo, &s.metallic_roughness, &s.occlusion, &s.emissive, &s.specular,
@@ -733,7 +733,7 @@ int pt_scene_set_materials(pt_ctx* ctx, const pt_material* m, int count) {
             const TextureRec& tx = ctx->textures[a.descriptor];
             const SamplerRec& sm = ctx->samplers[a.sampler];
             float sn = 0.0f, cs = 1.0f;                   // sin(0) = 0, cos(0) = 1 exactly
-            if (a.rotation != 0.0f) { sn = sinf(a.rotation); cs = cosf(a.rotation); }
+            if (a.rotation != 0.0f) { sn = (float)sin((double)a.rotation); cs = (float)cos((double)a.rotation); }
             t.texels = tx.texels; t.width = tx.width; t.height = tx.height;
             t.flags = (tx.srgb ? RT_SRGB : 0u) | ((uint32_t)sm.address_u << 1) | ((uint32_t)sm.address_v << 3) |
                       (sm.mag_filter == PT_FILTER_POINT ? RT_POINT : 0u) | ((a.tex_coord & 1) ? RT_TEXCOORD1 : 0u);

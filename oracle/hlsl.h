@@ -98,6 +98,12 @@ inline float3 lerp(float3 a, float3 b, float3 t) { return a + t * (b - a); }
 inline float4 lerp(float4 a, float4 b, float t) { return a + t * (b - a); }
 inline float sign(float x) { return x > 0 ? 1.0f : (x < 0 ? -1.0f : 0.0f); }  // sign(0) = 0
 inline float3 reflect(float3 i, float3 n) { return i - 2 * dot(n, i) * n; }
+// sin / cos: HLSL leaves their precision to the implementation.  The oracle DEFINES them as the correctly rounded value -- evaluated in
+// double, rounded once -- so that its images do not depend on which float routine (and which FMA variant of it) the host's libm picks;
+// the host's sinf / cosf are within 0.56 ulp of that but not always equal to it, and a last bit in a sampled direction is a different path
+// on a scene that amplifies rounding.  The HIP path evaluates them the same way (pt_math.h pt_sincos).
+inline float o_sin(float x) { return (float)std::sin((double)x); }
+inline float o_cos(float x) { return (float)std::cos((double)x); }
 // pow(x,y) = exp2(y*log2(x)): x<0 -> NaN, pow(0, y>0) = 0.
 inline float hpow(float x, float y) { return exp2f(y * log2f(x)); }
 inline float3 hpow(float3 v, float y) { return {hpow(v.x, y), hpow(v.y, y), hpow(v.z, y)}; }

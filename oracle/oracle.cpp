@@ -362,7 +362,7 @@ static VertexAttributes GetVertexAttributes(const Oracle& o, const Instance& in,
 // ---- Material.hlsli ----------------------------------------------------------------------------
 static inline float2 TransformUv(const TextureAddress& a, float2 uv) {          // :68-88
     float3x3 T = M3({1, 0, a.offset.x}, {0, 1, a.offset.y}, {0, 0, 1});
-    float c = cosf(a.rotation), s = sinf(a.rotation);
+    float c = o_cos(a.rotation), s = o_sin(a.rotation);
     float3x3 R = M3({c, s, 0}, {-s, c, 0}, {0, 0, 1});
     float3x3 S = M3({a.scale.x, 0, 0}, {0, a.scale.y, 0}, {0, 0, 1});
     float3x3 M = mul(T, mul(R, S));
@@ -432,7 +432,7 @@ static SurfaceProperties GetSurfaceProperties(Oracle& o, const SceneConstants& s
         float4 s = SampleTexture(o, m.anisotropy, a.texcoords);
         av = {s.x * 2 - 1, s.y * 2 - 1, s.z};
     }
-    float cr = cosf(rot), sr = sinf(rot);
+    float cr = o_cos(rot), sr = o_sin(rot);
     float2 adir = normalize(float2{cr * av.x + -sr * av.y, sr * av.x + cr * av.y});
     strength *= av.z;
     // CalculateShadingTangentAndBitangent, Material.hlsli:264-270

@@ -82,7 +82,7 @@ inline void DecodeTangentSpace(float4 enc, float3& normal, float4& tangent) {   
     float3 ct, cb;
     CreateBasisAccurate(normal, ct, cb);
     float angle = TAU * enc.z;                                    // no -0.5: tangent comes out negated (quirk q25)
-    float3 t = cosf(angle) * ct + sinf(angle) * cb;
+    float3 t = o_cos(angle) * ct + o_sin(angle) * cb;
     tangent = {t.x, t.y, t.z, enc.w > 0 ? 1.f : -1.f};
 }
 // GPU-side encoder, Vertex.hlsli:21-44 (used by Skin.cs.hlsl:134).  No clamp on the tangent.
@@ -140,14 +140,14 @@ inline float2 UnitSquareToUv(float2 s) { return (s - float2{-1, 1}) * float2{0.5
 inline float2 SquareToDisk2(float2 s) {                             // :83-90
     float r = hmax(fabsf(s.x), fabsf(s.y));
     float phi = r == 0 ? 0 : (PI * (r + (fabsf(s.y) - fabsf(s.x))) / (4 * r));
-    return {sign(s.x) * r * cosf(phi), sign(s.y) * r * sinf(phi)};
+    return {sign(s.x) * r * o_cos(phi), sign(s.y) * r * o_sin(phi)};
 }
 inline float3 SquareToSphere(float2 s) {                            // :124-136
     float d = 1 - (fabsf(s.x) + fabsf(s.y));
     float r = 1 - fabsf(d);
     float phi = (r == 0) ? 0 : (PI / 4) * ((fabsf(s.y) - fabsf(s.x)) / r + 1);
     float f = r * sqrtf(2 - r * r);
-    return {f * sign(s.x) * cosf(phi), f * sign(s.y) * sinf(phi), sign(d) * (1 - r * r)};
+    return {f * sign(s.x) * o_cos(phi), f * sign(s.y) * o_sin(phi), sign(d) * (1 - r * r)};
 }
 inline float2 SphereToSquare(float3 p) {                            // :138-149
     float r = sqrtf(1 - fabsf(p.z));
@@ -185,8 +185,8 @@ inline LightRay GetLightRay(const Light& light, float3 p) {         // :26-61
     }
     ray.direction = normalize(ray.direction);
     if (light.type == 1) {
-        float scale = 1.0f / hmax(0.001f, cosf(light.inner_angle) - cosf(light.outer_angle));
-        float offset = -cosf(light.outer_angle) * scale;
+        float scale = 1.0f / hmax(0.001f, o_cos(light.inner_angle) - o_cos(light.outer_angle));
+        float offset = -o_cos(light.outer_angle) * scale;
         float cd = -dot(normalize(light.direction), ray.direction);
         float att = saturate(cd * scale + offset);
         att *= att;
@@ -347,7 +347,7 @@ inline float3 SampleCosineWeightedHemisphere(float3 n, float2 u) {  // :26-33
     float theta = TAU * u.x;
     u.y = 2 * u.y - 1;
     float s = sqrtf(1.0f - u.y * u.y);
-    float3 sphere = {s * cosf(theta), s * sinf(theta), u.y};
+    float3 sphere = {s * o_cos(theta), s * o_sin(theta), u.y};
     return normalize(n + sphere);
 }
 inline float CosineWeightedHemispherePdf(float3 n, float3 v) { return saturate(dot(v, n) / PI); }   // :35-38
@@ -355,7 +355,7 @@ inline float3 SampleGgxNormal(float a, float2 u) {                  // :41-52
     float phi = TAU * u.x;
     float cos_theta = sqrtf((1 - u.y) / (1 + (a * a - 1) * u.y));
     float sin_theta = sqrtf(1 - cos_theta * cos_theta);
-    return {sin_theta * cosf(phi), sin_theta * sinf(phi), cos_theta};
+    return {sin_theta * o_cos(phi), sin_theta * o_sin(phi), cos_theta};
 }
 inline float GgxNormalPdf(float a, float3 n, float3 h) { float ndh = dot(n, h); return GgxD(a, ndh) * ndh; }  // :54-58
 inline float3 SampleGgxAnisotropicNormal(float2 a, float2 u) {      // :60-65

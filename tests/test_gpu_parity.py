@@ -157,7 +157,7 @@ def test_material_grid_deep_bounces(R, oracle_lib):
     # side only leaves a saturated pixel: with an FMA-contracting build this scene sat at 1.1e-3 ... 2.8e-3 (different events each time) and
     # only its bulk met the bar.  Since the path-tracing kernels are built like the oracle -- no floating-point contraction (csrc/Makefile) --
     # the WHOLE image meets it: measured 4.8e-5, and 8e-6 (2.4e-7 without the 16 worst pixels, no pixel beyond 0.05) since sin / cos are
-    # evaluated in double and rounded once like the oracle's libm (pt_math.h).  Both figures are asserted.
+    # evaluated in double and rounded once (pt_math.h), and 1.8e-7 once the oracle defines them the same way (hlsl.h o_sin / o_cos).
     p = Pair(R, oracle_lib, scenes.material_grid(128, seg=12))
     og, b = p.render(frames=96)
     ta, tb = p.r.tonemap(og).astype(np.float64), po.tonemap(b).astype(np.float64)
@@ -174,7 +174,7 @@ def test_material_grid_deep_bounces(R, oracle_lib):
     st = p.r.stats(); c = p.o.counters()
     assert abs(int(st.rays) - c["rays"]) <= 5e-4 * c["rays"]
     assert e <= 1e-3, e                                             # the north_star bar, whole image
-    assert e <= 1e-4 and trimmed <= 1e-5 and (d > 0.05).sum() == 0 and float(np.median(d)) < 1e-6 and abs(bias) < 1e-5, (e, trimmed, int((d > 0.05).sum()), float(np.median(d)), bias)
+    assert e <= 1e-5 and trimmed <= 1e-5 and (d > 0.05).sum() == 0 and float(np.median(d)) < 1e-6 and abs(bias) < 1e-5, (e, trimmed, int((d > 0.05).sum()), float(np.median(d)), bias)   # measured 1.8e-7
     p.close()
 
 
@@ -520,7 +520,7 @@ def test_fullsize_scene_hits_and_radiance_match_the_oracle(R, oracle_lib):
     # build parted from the plain-arithmetic oracle in 0.3 % of the pixel-samples at one bounce and 2 % at four.  Built without contraction
     # (csrc/Makefile) the kernels agreed in every pixel-sample at one bounce and in all but 0.04 % at four; with sin / cos evaluated in
     # double and rounded once, like the oracle's libm (pt_math.h), in every pixel-sample at four bounces too.  Counted and bounded.
-    for mb, frac_1pc in ((1, 1e-4), (4, 2e-4)):
+    for mb, frac_1pc in ((1, 1e-5), (4, 1e-5)):
         st = copy_settings(s.settings); st.max_bounces = mb; st.min_bounces = min(st.min_bounces, mb); st.flags &= ~abi.FLAG_ACCUMULATE
         st.use_frame_as_seed = 0; st.seed = 9
         og, b = p.render(settings=st)

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../gltf_renderer_amd/csrc"
 mkdir -p ../../variants /tmp/variant_$NAME
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable -Wno-unused-value -I../../include $@"
 for f in pt_wavefront pt_kernel accel; do
-  X=""; [ $f != accel ] && X="-fno-slp-vectorize -ffp-contract=off"      # as in the Makefile: the path-tracing kernels without the SLP vectoriser and without contraction
+  X="-ffp-contract=off"; [ $f != accel ] && X="-fno-slp-vectorize -ffp-contract=off"      # as in the Makefile: no contraction anywhere, the path-tracing kernels also without the SLP vectoriser
   /opt/rocm/bin/hipcc $FLAGS $X -c $f.hip -o /tmp/variant_$NAME/$f.o &
 done
 wait
