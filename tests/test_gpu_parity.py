@@ -186,15 +186,10 @@ def test_env_preprocessing_matches_oracle(R, oracle_lib):
     o = oracle_lib.Oracle(); eo = o.env_create(img)
     n2, cube2, pyr2 = o.env_read(eo)
     assert n == n2 == 65
-    assert (cube[..., :3] != cube2[..., :3]).mean() < 0.02       # half texels: last-bit rounding differences only
-    fa = cube[..., :3].view(np.float16).astype(np.float32); fb = cube2[..., :3].view(np.float16).astype(np.float32)
-    fin = np.isfinite(fa) & np.isfinite(fb)
-    assert np.array_equal(np.isfinite(fa), np.isfinite(fb))
-    assert np.abs(fa[fin] - fb[fin]).max() <= 2e-3 * np.abs(fb[fin]).max()
-    assert np.all(cube[..., 3] == cube2[..., 3])
-    tot = pyr2[-1]
-    assert abs(pyr[-1] - tot) <= 2e-4 * tot
-    assert np.abs(pyr[:1024 * 1024] - pyr2[:1024 * 1024]).max() <= 2e-3 * pyr2[:1024 * 1024].max()
+    # built without contraction (csrc/Makefile) the four kernels reproduce the oracle bit for bit: every RGBA16F cube texel, every entry of
+    # the 1024^2 map and of its ten-level sum pyramid (with an FMA-contracting build 2 % of the texels differed in the last bit)
+    assert np.array_equal(cube, cube2), int((cube != cube2).sum())
+    assert np.array_equal(pyr.view(np.uint32), pyr2.view(np.uint32)), int((pyr.view(np.uint32) != pyr2.view(np.uint32)).sum())
     r.close(); o.close()
 
 
