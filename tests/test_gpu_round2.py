@@ -758,15 +758,17 @@ def test_interleaved_copies_follow_the_material_table(R):
     r.close()
 
 
-@pytest.mark.parametrize("which", ["all_features", "sponza_class"])
+@pytest.mark.parametrize("which", ["all_features", "sponza_class", "material_grid", "helmet_class"])
 def test_first_vertex_quantities_are_bit_identical_to_the_oracle(R, oracle_lib, which):
     """Every debug output of the reference (Pathtracer.h:19-49: the per-pixel deterministic quantities of the first path vertex) rendered on
     both sides and compared BIT FOR BIT.  Built without contraction and with sin / cos correctly rounded on both sides, the HIP path
     reproduces all of them exactly -- hit kind, vertex attributes, texture coordinates, albedo, the shading frame, every material scalar, the
     sampled bounce direction -- except the BSDF value and the pdf / weight formed from it: its pow is v_exp_f32(y * v_log_f32(x)) here and
     libm's exp2f(y * log2f(x)) in the oracle, both within an ulp (measured: <= 6e-7 relative in ~10 % of the pixels)."""
-    s = scenes.test_scene(160, 64) if which == "all_features" else scenes.sponza_class(width=320, height=180, tex=64)
+    s = {"all_features": lambda: scenes.test_scene(160, 64), "sponza_class": lambda: scenes.sponza_class(width=320, height=180, tex=64),
+         "material_grid": lambda: scenes.material_grid(256, seg=16), "helmet_class": lambda: scenes.helmet_class(width=320, height=180, subdiv=4, tex=256)}[which]()
     r = R(); hg = s.upload(r)
+    if s.bounce_limit != 5: r.set_bounce_limit(s.bounce_limit)
     o = oracle_lib.Oracle(); ho = s.upload(o, env_raw=r.env_read(hg["env"]) if hg["env"] is not None else None)
     og = r.create_output(s.width, s.height); b = np.zeros((s.height, s.width, 4), np.float32)
     rounding_only = {abi.DEBUG_OUTPUT_BOUNCE_BSDF, abi.DEBUG_OUTPUT_BOUNCE_PDF, abi.DEBUG_OUTPUT_BOUNCE_WEIGHT}

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run ON THE GPU BOX: which of the reference's debug outputs (per-pixel deterministic quantities of the first path vertex) does the HIP path
-reproduce BIT FOR BIT against the oracle, and which only to rounding?  usage: python tools/diag_bit_audit.py [sponza|test]"""
+reproduce BIT FOR BIT against the oracle, and which only to rounding?  usage: python tools/diag_bit_audit.py [sponza|test|grid|helmet|figure]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,7 +8,8 @@ from gltf_renderer_amd import abi, scenes
 from gltf_renderer_amd.renderer import Renderer
 from oracle import pyoracle
 which = sys.argv[1] if len(sys.argv) > 1 else "sponza"
-s = scenes.sponza_class(width=320, height=180, tex=64) if which == "sponza" else scenes.test_scene(160, 64)
+s = {"sponza": lambda: scenes.sponza_class(width=320, height=180, tex=64), "test": lambda: scenes.test_scene(160, 64), "grid": lambda: scenes.material_grid(256, seg=16),
+     "helmet": lambda: scenes.helmet_class(width=320, height=180, subdiv=4, tex=256), "figure": lambda: scenes.skinned_figure(320, 180)}[which]()
 r = Renderer(); hg = s.upload(r)
 o = pyoracle.Oracle(); ho = s.upload(o, env_raw=r.env_read(hg["env"]) if hg["env"] is not None else None)
 og = r.create_output(s.width, s.height); b = np.zeros((s.height, s.width, 4), np.float32)
