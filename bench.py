@@ -16,20 +16,27 @@ image, and ONE exchange per step assembles the frame on rank 0 -- `pt_exchange_f
 stream: every rank sends its own tiles point to point over its direct xGMI link, or `--exchange reduce`: ncclReduce of a
 zero-masked copy).  The headline line is STRONG scaling: the same 8-spp step split N ways (total work fixed, the BASELINE metric
 on N GPUs).  The same run then times the WEAK variant (8 x N samples per step: per-GPU work fixed) and reports it in
-`weak_scaling`.  `--backend gloo --single-device` rehearses the rank logic on one GPU through the torch.distributed test double
-(gltf_renderer_amd/sharding.py); RCCL itself needs one GPU per rank.
+`weak_scaling`.  `python bench.py --gpus N` started plainly (no WORLD_SIZE) launches its own N ranks with torch.distributed.run as a
+child process before anything touches a GPU, and exits non-zero if the node has fewer than N devices; the line's `n_gpus` is always the
+number of ranks that rendered.  If RCCL cannot be brought up inside libmipt.so on every rank the run FAILS (no fallback transport).
+`--backend gloo --single-device` rehearses the rank logic on one GPU through the torch.distributed test double
+(tests/sharding_double.py) and says so in the line; RCCL itself needs one GPU per rank.  The N > 1 branches of the library's own
+exchange_frame are tested on one GPU through its in-process loopback transport (tests/test_gpu_round3.py).
 
 Timed region: inputs (scene, BVH, textures, env maps) resident in HBM; K steps bracketed by barrier + torch.cuda.synchronize on
 both sides; time = max over ranks; value = rays traced by all ranks in the K steps / that time.  Rays are counted by the kernels
 (every traversal started).  The accumulation is reset before it could reach max_accumulated_frames, so no timed step is a no-op.
 
 Extra objects on the JSON line (rank 0, N = 1):
-  roofline     - for the DOMINANT KERNEL of the pipeline (the stage with the largest share of a launch's time): achieved =
-                 its algorithmic bytes per launch / its time per launch (HIP events after every stage launch on the launch
-                 stream, untimed replay of the same frames without counters); peak = 8 TB/s.  `stages` holds the same for every
-                 stage with the roof that applies to it (cache-gather ceilings of MI355X_MICROARCH.md for the traversal stages),
-                 LDS-resident table bytes and fetched bytes apart; `pipeline` the whole launch.  `traffic` = PMC-measured HBM
-                 bytes of that kernel per launch from profiles/ (separate rocprofv3 --pmc passes), `traffic_source` says which file.
+  roofline     - for the single DOMINANT KERNEL (largest share of a launch's GPU time; k_wf_traverse): achieved = its algorithmic
+                 bytes per launch / its time per launch (HIP events after every stage launch on the launch stream, untimed replay
+                 of the same frames; bytes from two counting replays, the second with max_bounces 0 to split off the primary
+                 rays).  `peak` is a figure of MI355X_MICROARCH.md: the traversal kernels are cache-fed (PMC: the fabric moves a
+                 fifth of their algorithmic bytes), so bound = "l2-gather" at the guide's 16.8 TB/s, with frac_of_hbm_peak
+                 (8 TB/s) and frac_of_infinity_cache_gather (8.6 TB/s) beside it; the shade stage is priced against HBM.
+                 `kernels` / `stages` hold the same for every kernel / kernel family, `own_probe_ceilings` the builder's own
+                 measured ceilings (never the peak).  `traffic` = PMC-measured fabric bytes of that kernel per launch from
+                 profiles/r03_pmc_per_kernel.json (separate --pmc passes), stamped with the git head they were collected at.
   cpu_baseline - the CPU oracle (kind "port": the reference has no CPU tracer and no CPU BVH build) on a bounded sample of the same
                  workload: all-core and 1-thread Mrays/s with the CPU model, plus `legs`: B2 CPU LBVH build vs the HIP build and
                  refit, B3 the restated per-frame host work (gs_animate + global transforms + gs_frame) in microseconds, B4 CPU
@@ -85,6 +92,23 @@ def main():
     ap.add_argument("--rebuild", action="store_true", help="with --animate: full LBVH rebuild every frame instead of the refit (the round-1 behaviour, for comparison)")
     args = ap.parse_args()
 
+    # ---- `python bench.py --gpus N` with no launcher around it: start the N ranks ourselves, as a child process, BEFORE any GPU call
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import subprocess
+        import torch
+        have = torch.cuda.device_count()              # counting devices does not initialise the GPU
+        if have < args.gpus and not args.single_device:
+            raise SystemExit("bench.py: --gpus %d asked for, %d device(s) visible on this node" % (args.gpus, have))
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -92,18 +116,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:                            # the line's n_gpus is the number of ranks that render: never report another
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE %d (launch with --nproc-per-node %d, or start bench.py plainly and it launches its own ranks)"
+                         % (args.gpus, world, args.gpus))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.single_device:
             local_rank = 0
+        elif torch.cuda.device_count() < world:
+            raise SystemExit("bench.py: %d ranks but %d device(s) visible" % (world, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="gloo")
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
     from gltf_renderer_amd import scenes, abi
     from gltf_renderer_amd.renderer import Renderer
@@ -150,24 +177,26 @@ def main():
     xch = None
     exchange_impl = "libmipt.so (RCCL)"
     if world > 1 and args.backend == "nccl":
-        # the library's own exchange; should RCCL refuse to come up inside the library on some node (every rank must agree, hence
-        # the all-reduce of the outcome), the same exchange runs through torch.distributed on device tensors and the line says so
-        ok = 1
-        try:
-            ids = [r.exchange_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)            # the host's transport for the 128-byte ncclUniqueId
-            r.exchange_create(rank, world, ids[0])
-        except Exception as e:                                # noqa: BLE001
-            print("rank %d: pt_exchange_create failed (%s)" % (rank, e), file=sys.stderr)
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        # The library's own exchange, or no run at all.  ncclCommInitRank is collective, so the ranks first AGREE that every one of them
+        # can load RCCL (a probe that touches neither the GPU nor the network) before any of them enters it; every rank always takes part
+        # in the broadcast of the id, whatever happened on rank 0.
+        flag = torch.tensor([1 if Renderer.exchange_probe() else 0], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
-            from gltf_renderer_amd.sharding import TileExchange
-            xch = TileExchange(s.width, s.height, world, "cuda")
-            exchange_impl = "torch.distributed fallback (pt_exchange_create failed on a rank)"
+            raise SystemExit("bench.py: librccl cannot be loaded inside libmipt.so on at least one rank (rank %d: %s): no exchange, no run"
+                             % (rank, "ok" if Renderer.exchange_probe() else "failed"))
+        ids = [None]
+        if rank == 0:
+            try:
+                ids = [r.exchange_unique_id()]
+            except Exception as e:                            # noqa: BLE001
+                print("rank 0: pt_exchange_unique_id failed (%s)" % e, file=sys.stderr)
+        dist.broadcast_object_list(ids, src=0)                # the host's transport for the 128-byte ncclUniqueId
+        if ids[0] is None:
+            raise SystemExit("bench.py: rank 0 could not make an ncclUniqueId")
+        r.exchange_create(rank, world, ids[0])                # raises on failure: the launcher takes the job down
     elif world > 1:
-        from gltf_renderer_amd.sharding import TileExchange
+        from tests.sharding_double import TileExchange
         xch = TileExchange(s.width, s.height, world, "cpu")
         exchange_impl = "torch.distributed test double over gloo"
 
@@ -176,10 +205,6 @@ def main():
             return
         if xch is None:                     # product path: RCCL inside the library, on the launch stream, assembled in place on rank 0
             r.exchange_frame(img, None, mode=abi.EXCHANGE_GATHER if exchange_mode == "gather" else abi.EXCHANGE_REDUCE, dst=0)
-        elif args.backend == "nccl":        # fallback: the same exchange through torch.distributed on device tensors
-            res = xch.gather_frame(img, rank) if exchange_mode == "gather" else xch.reduce_frame(img, rank)
-            if rank == 0 and res is not img:
-                img.copy_(res)
         else:                               # rehearsal: gloo moves host tensors
             host = img.cpu()
             res = xch.gather_frame(host, rank) if exchange_mode == "gather" else xch.reduce_frame(host, rank)
@@ -324,112 +349,150 @@ def main():
         result["config"]["dynamic_ms"]["first_build_ms"] = round(accel_ms, 4)
         result["config"]["parallelism"] += "; skin (MFMA joint blend) + %s + 1 spp trace per step" % ("full LBVH rebuild" if args.rebuild else "BVH refit")
 
-    # ---- roofline (rank 0, N = 1): stage times from an untimed replay with an event after every stage launch, then the same
-    # frames once more with the node / triangle / hit / tap counters on (the counting kernels are slower, so they are never timed)
+    # ---- roofline (rank 0, N = 1): stage times from an untimed replay with an event after every stage launch (HIP events on the launch
+    # stream, inside the library), then the same frames twice more with the node / triangle / hit / tap counters on -- once as they are
+    # and once with max_bounces = 0, which isolates the primary rays' share (the counting kernels are slower, so they are never timed)
     if rank == 0 and world == 1 and not args.no_roofline and args.mode == "wavefront":
         settings2 = abi.PtSettings.from_buffer_copy(bytes(settings))
         out2 = r.create_output(s.width, s.height)
         n = float(args.steps)
+
+        def replay(st, per_step=None):
+            st.reset = 1
+            for k in range(args.steps):
+                animate(args.warmup + k)
+                if binding is not None:
+                    st.reset = 1
+                r.trace(st, s.execute_params(frame=(args.warmup + k) * spp, env_handle=h["env"]), out2)
+                st.reset = 0
+                if per_step:
+                    per_step()
+
         stage_ms = [0.0] * 5
-        r.enable_stage_timing(True)
-        settings2.reset = 1
-        for k in range(args.steps):
-            animate(args.warmup + k)
-            if binding is not None:
-                settings2.reset = 1
-            r.trace(settings2, s.execute_params(frame=(args.warmup + k) * spp, env_handle=h["env"]), out2)
-            settings2.reset = 0
+
+        def add_stage_ms():
             q = r.stats()
             for i in range(5):
                 stage_ms[i] += q.stage_ms[i] / n
+
+        r.enable_stage_timing(True)
+        replay(settings2, add_stage_ms)
         r.enable_stage_timing(False)
         r.enable_counters(True)
         torch.cuda.synchronize()
         r.reset_stats()
-        settings2.reset = 1
-        for k in range(args.steps):
-            animate(args.warmup + k)
-            if binding is not None:
-                settings2.reset = 1
-            r.trace(settings2, s.execute_params(frame=(args.warmup + k) * spp, env_handle=h["env"]), out2)
-            settings2.reset = 0
+        replay(settings2)
         c = r.stats()
+        settings0 = abi.PtSettings.from_buffer_copy(bytes(settings)); settings0.max_bounces = 0; settings0.min_bounces = 0
+        r.reset_stats()
+        replay(settings0)
+        c0 = r.stats()                        # the same frames, primary rays only: k_wf_trace's node steps and triangle tests
         r.enable_counters(False)
         env_mis = bool(settings.flags & abi.FLAG_ENVIRONMENT_MIS) and bool(settings.flags & abi.FLAG_ENVIRONMENT_MAP)
         # bytes/ray = N_node*64 + N_tri*48 + [closest hits] S_hit + [misses] 64 + 32/R per pixel-sample; S_hit = 12 (indices)
         # + 72 (three vertices) + 176 (instance row) + 640 (material) + 16 per bilinear footprint + 160 (importance pyramid) with env MIS
         misses = c.rays_primary + c.rays_bounce - c.closest_hits
-        # traversal = k_wf_trace (primary rays) + k_wf_traverse (the shadow rays of a bounce and the closest-hit rays of the next,
-        # fused in one launch) + the last k_wf_shadow; the counters still tell the two ray kinds apart
+        primary_nodes = c0.nodes_visited - c0.nodes_visited_shadow
+        primary_tris = c0.tris_tested - c0.tris_tested_shadow
         alg = {"traversal": (c.nodes_visited * 64 + c.tris_tested * 48) / n,
                "shade": (c.closest_hits * (12 + 72 + 176 + 640 + (160 if env_mis else 0)) + c.texture_taps * 16 + misses * 64) / n,
                "generate+resolve": float(s.width * s.height * 32 * spp)}
         split = {"closest_hit_rays": {"rays": (c.rays_primary + c.rays_bounce) / n, "nodes": (c.nodes_visited - c.nodes_visited_shadow) / n, "tris": (c.tris_tested - c.tris_tested_shadow) / n},
-                 "shadow_rays": {"rays": c.rays_shadow / n, "nodes": c.nodes_visited_shadow / n, "tris": c.tris_tested_shadow / n}}
+                 "shadow_rays": {"rays": c.rays_shadow / n, "nodes": c.nodes_visited_shadow / n, "tris": c.tris_tested_shadow / n},
+                 "primary_rays": {"rays": c0.rays_primary / n, "nodes": primary_nodes / n, "tris": primary_tris / n}}
         # what the shade stage reads from tables it staged into LDS once per workgroup (material header + three slots, the 96-B
         # instance row, the three coarsest level pairs of the importance pyramid) instead of fetching per hit
         lds = c.closest_hits * (640 + 176 + (96 if env_mis else 0)) / n
         ms = {"traversal": stage_ms[1] + stage_ms[3], "shade": stage_ms[2], "generate+resolve": stage_ms[0] + stage_ms[4]}
-        # roofs: the traversal stages gather 64-B nodes / 48-B triangle packets that live in the L2s and the Infinity Cache, so their roof is
-        # the MEASURED gather ceiling of that very access pattern at their occupancy (tools/probes/quadload_probe.hip, profiles/
-        # r02e_microbenchmarks.txt: 200 G node fetches/s = 12.8 TB/s L2-resident, 65 G/s = 4.2 TB/s Infinity-Cache-resident; the guide's
-        # figures: L2 gather 16.8-18.8 TB/s, Infinity-Cache gather 8.6 TB/s); the shade stage's scattered lines come from HBM.
-        roofs = {"traversal": ("L2-resident 64-B gather, measured with this access pattern at 6 waves/SIMD (tools/probes/quadload_probe.hip: 12.8 TB/s; "
-                               "Infinity-Cache-resident 4.2 TB/s; MI355X_MICROARCH.md: L2 gather 16.8-18.8, Infinity-Cache gather 8.6 TB/s)", 12800.0),
-                 "shade": ("HBM", 8000.0), "generate+resolve": ("HBM", 8000.0)}
-        pmc = {}
-        pmc_file = os.path.join("profiles", "r02_pmc_per_kernel.json")
+        # The individual kernels of the traversal family: k_wf_trace = the primary rays (stage events of kind "trace"); k_wf_traverse = the
+        # shadow rays of a bounce + the closest-hit rays of the next, fused (stage events of kind "shadow", which also hold the one
+        # k_wf_shadow launch that ends a pt_trace: ~1 % of them)
+        kernels = {"k_wf_trace": {"ms_per_launch": stage_ms[1], "algorithmic_bytes_per_launch": (primary_nodes * 64 + primary_tris * 48) / n, "launches_per_pt_trace": 1},
+                   "k_wf_traverse": {"ms_per_launch": stage_ms[3], "algorithmic_bytes_per_launch": alg["traversal"] - (primary_nodes * 64 + primary_tris * 48) / n,
+                                     "launches_per_pt_trace": int(settings.max_bounces), "note": "includes the pt_trace's last k_wf_shadow launch (no bounce rays left to fuse)"},
+                   "k_wf_shade": {"ms_per_launch": stage_ms[2], "algorithmic_bytes_per_launch": alg["shade"], "launches_per_pt_trace": int(settings.max_bounces) + 1}}
+        # Roofs, every one a figure of /opt/skills/guides/MI355X_MICROARCH.md (the builder's own probe ceilings ride beside them as extra keys):
+        #   HBM 8.0 TB/s spec (6.29 achievable)                                         :36, section HBM
+        #   L2-resident gather 16.8-18.8 TB/s, Infinity-Cache-resident gather 8.6 TB/s   section "Indexed rows: gather into LDS", table
+        # The traversal kernels gather 64-B nodes and 48-B triangle packets that live in the L2s and the Infinity Cache (PMC: the fabric moves
+        # a fifth of their algorithmic bytes), so HBM is not their roof: they are priced against the guide's L2 gather rate (lower figure).
+        GUIDE = {"hbm_peak_GBps": 8000.0, "hbm_achievable_GBps": 6290.0, "l2_gather_GBps": [16800.0, 18800.0], "infinity_cache_gather_GBps": 8600.0,
+                 "source": "MI355X_MICROARCH.md: chip table 'HBM3E peak BW', section 'HBM', section 'Indexed rows: gather into LDS'"}
+        OWN = {"l2_resident_64B_node_gather_GBps": 12800.0, "infinity_cache_resident_64B_node_gather_GBps": 4200.0, "random_128B_lines_from_hbm_GBps": 6400.0,
+               "source": "tools/probes/quadload_probe.hip, random_sector_probe.hip (profiles/r02e_microbenchmarks.txt): this pipeline's own access patterns; not the roofline's peak"}
+        roofs = {"traversal": ("l2-gather", GUIDE["l2_gather_GBps"][0]), "shade": ("hbm", GUIDE["hbm_peak_GBps"]), "generate+resolve": ("hbm", GUIDE["hbm_peak_GBps"])}
+        pmc, pmc_kernels, pmc_head = {}, {}, None
+        pmc_file = os.path.join("profiles", "r03_pmc_per_kernel.json")
         if os.path.exists(os.path.join(ROOT, pmc_file)) and args.config == "sponza" and not (args.width or args.height or args.animate):
             try:
                 pm = json.load(open(os.path.join(ROOT, pmc_file)))
                 if pm.get("samples_per_launch", 1) == spp:
-                    pmc = pm.get("stages", {})
+                    pmc, pmc_kernels, pmc_head = pm.get("stages", {}), pm.get("kernels", {}), pm.get("git_head")
             except Exception:
                 pmc = {}
+
+        def entry(bytes_, ms_, roof):
+            gbs = bytes_ / max(ms_, 1e-9) / 1e6
+            return {"ms_per_launch": round(ms_, 4), "algorithmic_bytes_per_launch": round(bytes_), "achieved_GBps": round(gbs, 1),
+                    "bound": roof[0], "peak_GBps": roof[1], "frac": round(gbs / roof[1], 4), "frac_of_hbm_peak": round(gbs / GUIDE["hbm_peak_GBps"], 4)}
+
         stages = {}
         for k2 in alg:
-            gbs = alg[k2] / max(ms[k2], 1e-9) / 1e6
-            e = {"ms_per_launch": round(ms[k2], 4), "algorithmic_bytes_per_launch": round(alg[k2]), "achieved_GBps": round(gbs, 1),
-                 "roof": roofs[k2][0], "roof_GBps": roofs[k2][1], "frac_of_roof": round(gbs / roofs[k2][1], 4), "frac_of_hbm_peak": round(gbs / 8000.0, 4)}
+            e = entry(alg[k2], ms[k2], roofs[k2])
             if k2 == "traversal":
+                e["frac_of_l2_gather_upper"] = round(e["achieved_GBps"] / GUIDE["l2_gather_GBps"][1], 4)
+                e["frac_of_infinity_cache_gather"] = round(e["achieved_GBps"] / GUIDE["infinity_cache_gather_GBps"], 4)
                 e["split"] = {k3: {k4: round(v4, 1) for k4, v4 in v3.items()} for k3, v3 in split.items()}
             if k2 == "shade":
                 e["lds_table_bytes_per_launch"] = round(lds)
                 e["fetched_bytes_per_launch"] = round(alg[k2] - lds)
                 e["fetched_GBps"] = round((alg[k2] - lds) / max(ms[k2], 1e-9) / 1e6, 1)
+                e["frac_fetched_of_hbm_peak"] = round(e["fetched_GBps"] / GUIDE["hbm_peak_GBps"], 4)
             if k2 in pmc:
                 e["pmc"] = pmc[k2]
+                e["hbm_traffic_GBps"] = round(pmc[k2]["hbm_bytes_per_launch"] / max(ms[k2], 1e-9) / 1e6, 1)
+                e["hbm_traffic_frac_of_hbm_peak"] = round(e["hbm_traffic_GBps"] / GUIDE["hbm_peak_GBps"], 4)
+                e["traffic_over_algorithmic"] = round(pmc[k2]["hbm_bytes_per_launch"] / max(alg[k2] - (lds if k2 == "shade" else 0.0), 1.0), 3)
             stages[k2] = e
-        # the kernel family with the largest share of a launch: k_wf_shade, or the traversal kernels (k_wf_traverse -- the shadow rays of a
-        # bounce and the closest-hit rays of the next -- with the primary rays' k_wf_trace and the last k_wf_shadow: one code path,
-        # trace_persistent, timed together by the stage events)
-        dominant = "traversal" if ms["traversal"] > ms["shade"] else "shade"
-        kernel_of = {"shade": "k_wf_shade", "traversal": "k_wf_traverse + k_wf_trace + k_wf_shadow (one traversal code path)"}
-        for k2 in ("traversal", "shade"):
-            if "pmc" in stages[k2]:     # what the counters say the stage moved, beside what the algorithm asks for
-                stages[k2]["hbm_traffic_GBps"] = round(stages[k2]["pmc"]["hbm_bytes_per_launch"] / max(ms[k2], 1e-9) / 1e6, 1)
-                stages[k2]["hbm_random_line_ceiling_GBps"] = 6400.0      # tools/probes/random_sector_probe.hip: ~50 G random 128-B lines/s
-        limiter = {"shade": "scattered cache lines from HBM (a gather is priced at its 128-B line: ~50 G random lines/s = 6.4 TB/s is the chip's ceiling, "
-                            "profiles/r02e_microbenchmarks.txt) and ~7 k dependent vector instructions per hit at 2 waves/SIMD (DESIGN.md section 4)",
-                   "traversal": "cache-gather rate, not HBM: nodes and triangle packets are L2 / Infinity-Cache resident (HBM traffic is a fifth of the algorithmic "
-                                "bytes); measured against the gather ceiling of the same access pattern (stages.traversal.roof), with ~160 vector instructions "
-                                "per node step that are not hidden (DESIGN.md section 4)"}
+        kout = {}
+        for kn, kv in kernels.items():
+            e = entry(kv["algorithmic_bytes_per_launch"], kv["ms_per_launch"], roofs["shade" if kn == "k_wf_shade" else "traversal"])
+            e["launches_per_pt_trace"] = kv["launches_per_pt_trace"]
+            if "note" in kv:
+                e["note"] = kv["note"]
+            if kn in pmc_kernels:
+                e["pmc"] = pmc_kernels[kn]
+            kout[kn] = e
+        # the single kernel with the largest share of a launch's GPU time
+        dominant = max(kernels, key=lambda kn: kernels[kn]["ms_per_launch"])
+        family = "shade" if dominant == "k_wf_shade" else "traversal"
+        limiter = {"shade": "scattered cache lines (a gather is priced at its 128-B line) and ~7 k dependent vector instructions per hit at 2 waves/SIMD (DESIGN.md section 4)",
+                   "traversal": "cache-gather rate, not HBM: nodes and triangle packets are L2 / Infinity-Cache resident (the fabric moves a fifth of the algorithmic bytes), "
+                                "with ~160 vector instructions per node step that are not hidden (DESIGN.md section 4)"}
         total_ms = sum(ms.values())
         mean_ms = sum(kernel_ms) / len(kernel_ms)
         total_alg = sum(alg.values())
-        d = stages[dominant]
-        traffic = pmc.get(dominant, {}).get("hbm_bytes_per_launch") if pmc else None
+        d = kout[dominant]
+        traffic = pmc_kernels.get(dominant, {}).get("hbm_bytes_per_launch") if pmc_kernels else None
         result["roofline"] = {
-            # `bound`: "hbm" when the shade stage dominates; the traversal kernels are fed by the L2s / the Infinity Cache, so pricing them
-            # against 8 TB/s of HBM gives a fraction above 1 that means nothing -- their peak is the measured gather ceiling (roofs above)
-            "bound": "hbm" if dominant == "shade" else "l2-gather",
-            "kernel": "%s (%.0f %% of a launch's GPU time; one launch = one pt_trace = %d sample(s) per pixel = %d launches of it)"
-                      % (kernel_of[dominant], 100.0 * ms[dominant] / max(total_ms, 1e-9), spp, settings.max_bounces + 1),
-            "achieved": d["achieved_GBps"], "peak": d["roof_GBps"], "unit": "GB/s", "frac": round(d["achieved_GBps"] / d["roof_GBps"], 5),
+            "kernel": dominant, "kernel_share_of_launch": round(kernels[dominant]["ms_per_launch"] / max(total_ms, 1e-9), 4),
+            "kernel_family": {"traversal": "k_wf_traverse + k_wf_trace + k_wf_shadow (one traversal code path, trace_persistent)", "shade": "k_wf_shade"}[family],
+            # `bound`: the traversal kernels are fed by the L2s and the Infinity Cache -- priced against 8 TB/s of HBM their fraction comes out
+            # above 1, which means "cache-served", not "beyond the roof" -- so their peak is the guide's L2 gather rate; frac_of_hbm_peak and
+            # frac_of_infinity_cache_gather are kept beside it, and hbm_traffic_* says what the HBM side actually moved (PMC)
+            "bound": d["bound"], "achieved": d["achieved_GBps"], "peak": d["peak_GBps"], "unit": "GB/s", "frac": round(d["achieved_GBps"] / d["peak_GBps"], 5),
+            "peak_source": GUIDE["source"], "guide_ceilings": GUIDE, "own_probe_ceilings": OWN,
             "frac_of_hbm_peak": d["frac_of_hbm_peak"],
-            "traffic": traffic, "traffic_source": (pmc_file + " (rocprofv3 --pmc passes of this command, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, summed over the kernel's launches of one pt_trace)") if traffic else None,
-            "limiter": limiter[dominant], "roof_that_applies": d["roof"],
-            "stages": stages,
+            "frac_of_infinity_cache_gather": round(d["achieved_GBps"] / GUIDE["infinity_cache_gather_GBps"], 4),
+            "ms_per_launch": d["ms_per_launch"], "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+            "one_launch": "one pt_trace = %d sample(s) per pixel; ms and bytes are sums over the kernel's %d launches inside it" % (spp, d["launches_per_pt_trace"]),
+            "traffic": traffic,
+            "traffic_frac_of_hbm_peak": round(traffic / max(d["ms_per_launch"], 1e-9) / 1e6 / GUIDE["hbm_peak_GBps"], 4) if traffic else None,
+            "traffic_source": (pmc_file + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command: (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950 correction of "
+                               "MI355X_MICROARCH.md section HBM; collected at git head " + str(pmc_head) + ", not in this run)") if traffic else None,
+            "traffic_git_head": pmc_head if traffic else None,
+            "limiter": limiter[family],
+            "family": stages[family], "kernels": kout, "stages": stages,
             "pipeline": {"kernel_ms_mean_timed": round(mean_ms, 4), "stage_ms_sum_replay": round(total_ms, 4), "algorithmic_bytes_per_launch": round(total_alg),
                          "achieved_GBps": round(total_alg / (mean_ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(total_alg / (mean_ms * 1e-3) / 1e9 / 8000.0, 4),
                          "pmc": pmc.get("pipeline")},

@@ -66,6 +66,7 @@ FILTER_POINT, FILTER_LINEAR = 0, 1
 MESH_FLAG_INDEX, MESH_FLAG_TANGENT_SPACE, MESH_FLAG_TEXCOORD_0 = 1, 2, 4
 MESH_FLAG_TEXCOORD_1, MESH_FLAG_COLOR, MESH_FLAG_JOINT_WEIGHT = 8, 16, 32
 DYNAMIC_MESH_FLAG_POSITION, DYNAMIC_MESH_FLAG_TANGENT_SPACE = 1, 2
+MAX_SIMULTANEOUS_MORPH_TARGETS = 4          # Source/Config.h:21
 TONEMAPPER_NONE, TONEMAPPER_AGX = 0, 1
 MODE_WAVEFRONT, MODE_MEGAKERNEL = 0, 1
 
@@ -237,7 +238,8 @@ class PtStats(C.Structure):
                 ("trace_ms", C.c_float), ("accel_ms", C.c_float), ("skin_ms", C.c_float),
                 ("accumulated_frames", C.c_int32), ("bvh_nodes", C.c_uint32), ("bvh_triangles", C.c_uint32),
                 ("nodes_visited_shadow", C.c_uint64), ("tris_tested_shadow", C.c_uint64), ("stage_ms", C.c_float * 5),
-                ("bvh_stack_need", C.c_uint32), ("accel_builds", C.c_uint32), ("accel_refits", C.c_uint32)]
+                ("bvh_stack_need", C.c_uint32), ("accel_builds", C.c_uint32), ("accel_refits", C.c_uint32),
+                ("bvh_stack_capacity", C.c_uint32), ("accel_builder_fallbacks", C.c_uint32), ("deep_stack_pushes", C.c_uint64)]
 
 
 STAGE_NAMES = ("generate", "trace", "shade", "shadow", "resolve")
@@ -254,4 +256,4 @@ assert C.sizeof(PtMeshInstance) == 156
 assert C.sizeof(PtInstanceDesc) == 176
 assert C.sizeof(PtExecuteParams) == 168
 assert C.sizeof(PtBone) == 128
-assert C.sizeof(PtStats) == 136
+assert C.sizeof(PtStats) == 152

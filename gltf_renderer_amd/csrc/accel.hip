@@ -891,9 +891,12 @@ static hipError_t ensure(AccelScratch& s, size_t n) {
     uint32_t* bounds = s.bounds;
     const int builder = s.builder, passes = s.reinsert_passes;
     const float min_gain = s.reinsert_min_gain;
+    const uint32_t fallbacks = s.fallbacks;
+    const std::string fallback_why = s.fallback_why;
     s = AccelScratch();
     s.bounds = bounds;
     s.builder = builder; s.reinsert_passes = passes; s.reinsert_min_gain = min_gain;
+    s.fallbacks = fallbacks; s.fallback_why = fallback_why;
     size_t cap = n + n / 8 + 64;
     hipError_t e;
     if ((e = hipMalloc(&s.tris_unsorted, cap * sizeof(TriPacket)))) return e;
@@ -974,7 +977,7 @@ static hipError_t ploc_build(AccelScratch& s, uint32_t n_tris, TriPacket* d_tris
     uint32_t bound = n_tris;
     int round = 0;
     for (;;) {
-        if (round > 4096) { s.why = "PLOC: more than 4096 clustering rounds"; return hipErrorUnknown; }   // every round merges at least the globally best pair; guards a hang
+        if (round > 4096) { s.why = "PLOC: more than 4096 clustering rounds"; return hipErrorNotReady; }   // every round merges at least the globally best pair; guards a hang
         for (int k = 0; k < 4; k++, round++) {                       // four rounds per look at the count
             const int a = round & 1;
             const dim3 grid((bound + 255) / 256);
@@ -990,7 +993,7 @@ static hipError_t ploc_build(AccelScratch& s, uint32_t n_tris, TriPacket* d_tris
         if ((e = hipMemcpyAsync(&n_cur, cnt + 4 + (round & 1), 4, hipMemcpyDeviceToHost, stream))) return e;
         if ((e = hipStreamSynchronize(stream))) return e;
         if (n_cur == bound && n_cur > 1) { s.why = "PLOC: no pair merged in four rounds at " + std::to_string(n_cur) + " clusters"; return hipErrorNotReady; }
-        if (n_cur == 0 || n_cur > bound) { s.why = "PLOC: cluster count " + std::to_string(n_cur) + " after round " + std::to_string(round) + " (bound " + std::to_string(bound) + ")"; return hipErrorUnknown; }
+        if (n_cur == 0 || n_cur > bound) { s.why = "PLOC: cluster count " + std::to_string(n_cur) + " after round " + std::to_string(round) + " (bound " + std::to_string(bound) + ")"; return hipErrorNotReady; }
         if (getenv("MIPT_DEBUG_PLOC")) fprintf(stderr, "PLOC round %d: %u clusters\n", round, n_cur);
         if (n_cur == 1) break;
         bound = n_cur;
@@ -1031,7 +1034,7 @@ static hipError_t ploc_build(AccelScratch& s, uint32_t n_tris, TriPacket* d_tris
     uint32_t fb = 1;
     const uint32_t n_nodes = n_tris - 1;
     for (uint32_t level = 0, cur = 0;;) {
-        if (level + 8 >= (uint32_t)kCollapseMaxLevels) { s.why = "PLOC: tree deeper than " + std::to_string(kCollapseMaxLevels) + " levels"; return hipErrorUnknown; }
+        if (level + 8 >= (uint32_t)kCollapseMaxLevels) { s.why = "PLOC: tree deeper than " + std::to_string(kCollapseMaxLevels) + " levels"; return hipErrorNotReady; }
         for (int j = 0; j < 8; j++, level++, cur ^= 1u) {
             hipLaunchKernelGGL(k_ploc_layout_level, dim3((fb + 255) / 256), dim3(256), 0, stream, (const int32_t*)s.ploc_left, (const int32_t*)s.ploc_right,
                                (const uint32_t*)s.ploc_count, (const uint32_t*)fn[cur], (const uint32_t*)ff[cur], (const uint32_t*)fi[cur], level, fn[cur ^ 1u], ff[cur ^ 1u],
@@ -1043,8 +1046,8 @@ static hipError_t ploc_build(AccelScratch& s, uint32_t n_tris, TriPacket* d_tris
         if ((e = hipMemcpyAsync(&next, cnt + kPlocLevelBase + level, 4, hipMemcpyDeviceToHost, stream))) return e;
         if ((e = hipMemcpyAsync(&bad, cnt + kPlocLayoutError, 4, hipMemcpyDeviceToHost, stream))) return e;
         if ((e = hipStreamSynchronize(stream))) return e;
-        if (bad) { s.why = "PLOC: the clustered links do not form a tree over the triangles (layout level " + std::to_string(level) + ")"; return hipErrorUnknown; }
-        if (next > n_nodes) { s.why = "PLOC: layout frontier of " + std::to_string(next) + " entries at level " + std::to_string(level); return hipErrorUnknown; }
+        if (bad) { s.why = "PLOC: the clustered links do not form a tree over the triangles (layout level " + std::to_string(level) + ")"; return hipErrorNotReady; }
+        if (next > n_nodes) { s.why = "PLOC: layout frontier of " + std::to_string(next) + " entries at level " + std::to_string(level); return hipErrorNotReady; }
         if (next == 0) break;
         fb = next;
     }
@@ -1077,9 +1080,11 @@ hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const Instan
     bool radix = s.builder == 0;
     if (!radix) {
         e = ploc_build(s, n_tris, d_tris, stream);
-        // the clustering must merge at least its globally best pair every round; if it ever does not (inconsistent arithmetic), the
-        // radix tree over the same, still untouched Morton order takes over rather than the build failing
-        if (e == hipErrorNotReady) { radix = true; (void)hipGetLastError(); }
+        // Every way the clustering can give up -- no pair merged in four rounds, the round cap (a monotone chain of clusters merges one
+        // pair a round), a layout that does not close, a tree deeper than the level cap -- is reported as hipErrorNotReady with s.why set,
+        // and all of them happen BEFORE k_ploc_gather rewrites d_tris: the radix tree over the same, still untouched Morton order (keys_b)
+        // takes over rather than the build failing.  The caller sees it in s.fallbacks / s.fallback_why.
+        if (e == hipErrorNotReady) { radix = true; s.fallbacks++; s.fallback_why = s.why; s.why.clear(); (void)hipGetLastError(); }
         else if (e) return e;
     }
     if (radix) hipLaunchKernelGGL(k_hierarchy, dim3(g), dim3(256), 0, stream, s.keys_b, (int)n_tris, s.nodes2, s.node_parent, s.leaf_parent);

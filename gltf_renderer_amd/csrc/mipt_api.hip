@@ -89,6 +89,7 @@ struct pt_ctx {
     void* d_workspace = nullptr; size_t workspace_cap = 0;     // wavefront ray / hit / path-state arrays
     void* d_tonemap = nullptr; size_t tonemap_cap = 0;         // pt_tonemap's device scratch (float RGB + RGBA8), reused
     pt::ExchangeState* exchange = nullptr;                         // pt_exchange_* (exchange.hip)
+    int32_t* d_deep = nullptr; size_t deep_cap = 0;                // deep traversal stack (SceneRec::deep_stack), only for trees that need > 64 entries
     bool stage_timing = false;                                 // pt_enable_stage_timing
     StageTimers timers;
     int kernel_mode = PT_MODE_WAVEFRONT;
@@ -296,13 +297,30 @@ public:
         ctx->accel_state = ACCEL_CLEAN;
         ctx->accel_built = true;
         std::fill(ctx->touched.begin(), ctx->touched.end(), (uint8_t)0);
-        // The build reports the most stack entries any ray can hold in this tree (a node pushes its other children).  A tree that
-        // needs more than rays have (long chains of equal Morton codes: thousands of coincident centroids) would silently drop
-        // pushes, i.e. geometry: refuse it here, loudly.  A refit keeps the topology, so the figure of the build stands.
-        if (!refit && (int)ctx->stack_need > traversal_stack_capacity()) {
+        // The build reports the most stack entries any ray can hold in this tree (a node pushes its other children).  A lane holds 64
+        // on chip (LDS + scratch).  A tree that needs more -- long chains of coincident centroids; the reference's driver BVH logs and
+        // skips only a primitive it cannot build, RayTracingAccelerationStructure.cpp:137-140 -- is never refused and never drops pushes:
+        // its rays get a deep stack in memory for the entries beyond 64 (SceneRec::deep_stack, sized at the next pt_trace).  Only a
+        // clustered tree deeper than kDeepStackMax entries is rebuilt as a radix tree, whose depth is bounded by the key (64 Morton
+        // bits + 32 index bits: at most 3 x 96 entries).  A refit keeps the topology, so the figure of the build stands.
+        if (!refit && ctx->stack_need > kDeepStackMax && ctx->scratch.builder != 0) {
+            const int chosen = ctx->scratch.builder;
+            ctx->scratch.builder = 0;
+            ctx->scratch.fallbacks++;
+            ctx->scratch.fallback_why = "clustered tree needs a traversal stack of " + std::to_string(ctx->stack_need) + " entries";
+            const hipError_t be = accel_build(ctx->scratch, ctx->d_buffers, ctx->d_instances, (int)ctx->instances.size(), ctx->n_tris, ctx->d_nodes, ctx->d_tris,
+                                              ctx->d_shade, &ctx->root, &ctx->wide_nodes, &ctx->stack_need, ctx->stream);
+            ctx->scratch.builder = chosen;
+            if (be != hipSuccess) {
+                ctx->accel_built = false; ctx->accel_state = ACCEL_REBUILD;
+                return ctx->fail(PT_ERR_DEVICE, std::string("acceleration-structure build (radix fallback): ") + (ctx->scratch.why.empty() ? hipGetErrorString(be) : ctx->scratch.why.c_str()));
+            }
+            HIPOK(hipEventRecord(ctx->ev_accel[1], ctx->stream));
+        }
+        if (!refit && ctx->stack_need > kDeepStackMax) {
             ctx->accel_built = false; ctx->accel_state = ACCEL_REBUILD;
-            return ctx->fail(PT_ERR_CAPACITY, "acceleration structure needs a traversal stack of " + std::to_string(ctx->stack_need) + " entries; rays have " +
-                                              std::to_string(traversal_stack_capacity()) + " (too many coincident triangle centroids)");
+            return ctx->fail(PT_ERR_CAPACITY, "acceleration structure needs a traversal stack of " + std::to_string(ctx->stack_need) + " entries (limit " +
+                                              std::to_string(kDeepStackMax) + ")");
         }
         return PT_OK;
     }
@@ -380,6 +398,22 @@ public:
             fc.div_pixel_slots = FastDiv::make(fc.pixel_slots); fc.div_tiles_x = FastDiv::make(fc.tiles_x);
             fc.seed_step = settings->use_frame_as_seed ? 1u : 0u;
 
+            // deep traversal stack (trees that need more than the 64 on-chip entries): (need - 64) entries for every lane of the widest
+            // traversal launch of this call
+            if ((int)ctx->stack_need > traversal_stack_capacity()) {
+                const uint32_t entries = (ctx->stack_need - (uint32_t)traversal_stack_capacity() + 7u) & ~7u;
+                size_t lanes;
+                if (ctx->kernel_mode == PT_MODE_MEGAKERNEL) lanes = (size_t)fc.my_tiles * 256;
+                else lanes = (size_t)traversal_grid_lanes(ctx->stage_blocks > 0 ? ctx->stage_blocks : stage_blocks_for((size_t)fc.pixel_slots * (size_t)batch));
+                const size_t need = (size_t)entries * lanes * 4;
+                if (need > ctx->deep_cap) {
+                    HIPOK(hipStreamSynchronize(ctx->stream));
+                    hipFree(ctx->d_deep); ctx->d_deep = nullptr; ctx->deep_cap = 0;
+                    if (hipMalloc((void**)&ctx->d_deep, need) != hipSuccess) { (void)hipGetLastError(); return ctx->fail(PT_ERR_OUT_OF_MEMORY, "deep traversal stack: " + std::to_string(need) + " bytes"); }
+                    ctx->deep_cap = need;
+                }
+                sc.deep_stack = ctx->d_deep; sc.deep_entries = entries; sc.deep_lanes = (uint32_t)lanes;
+            }
             HIPOK(hipEventRecord(ctx->ev_trace[0], ctx->stream));
             if (ctx->kernel_mode == PT_MODE_MEGAKERNEL) {
                 for (int k = 0; k < batch; k++) {                                        // the megakernel has no batch form: one launch per sample
@@ -569,6 +603,7 @@ void pt_destroy(pt_ctx* ctx) {
     hipFree(ctx->d_tonemap);
     hipFree(ctx->d_touched);
     exchange_free(ctx->exchange);
+    hipFree(ctx->d_deep);
     for (int k = 0; k < StagingRing::kSlots; k++) {
         if (ctx->staging.host[k]) hipHostFree(ctx->staging.host[k]);
         if (ctx->staging.done[k]) hipEventDestroy(ctx->staging.done[k]);
@@ -1047,6 +1082,10 @@ int pt_get_stats(pt_ctx* ctx, pt_stats* out) {
     out->bvh_nodes = ctx->wide_nodes;
     out->bvh_triangles = ctx->n_tris;
     out->bvh_stack_need = ctx->stack_need;
+    out->bvh_stack_capacity = (int)ctx->stack_need > traversal_stack_capacity() ? ((ctx->stack_need - (uint32_t)traversal_stack_capacity() + 7u) & ~7u) + (uint32_t)traversal_stack_capacity()
+                                                                               : (uint32_t)traversal_stack_capacity();
+    out->accel_builder_fallbacks = ctx->scratch.fallbacks;
+    out->deep_stack_pushes = c.deep_pushes;
     out->accel_builds = ctx->accel_builds; out->accel_refits = ctx->accel_refits;
     if (c.stack_overflow) return ctx->fail(PT_ERR_CAPACITY, "traversal stack overflow: " + std::to_string(c.stack_overflow) + " pushes dropped");
     return PT_OK;
@@ -1093,6 +1132,20 @@ int pt_exchange_create(pt_ctx* ctx, int rank, int world, const void* unique_id) 
     if (ctx->exchange) { HIPOK(hipStreamSynchronize(ctx->stream)); exchange_free(ctx->exchange); ctx->exchange = nullptr; }
     std::string err;
     const int rc = exchange_create(&ctx->exchange, rank, world, unique_id, err);
+    return rc == PT_OK ? PT_OK : ctx->fail(rc, err);
+}
+
+int pt_exchange_probe(void) {
+    std::string err;
+    return exchange_probe(err);
+}
+
+int pt_exchange_create_loopback(pt_ctx* ctx, int rank, int world, uint64_t group) {
+    if (!ctx || world < 1 || rank < 0 || rank >= world) return PT_ERR_INVALID_ARGUMENT;
+    ENTER(ctx);
+    if (ctx->exchange) { HIPOK(hipStreamSynchronize(ctx->stream)); exchange_free(ctx->exchange); ctx->exchange = nullptr; }
+    std::string err;
+    const int rc = exchange_create_loopback(&ctx->exchange, rank, world, group, ctx->device, err);
     return rc == PT_OK ? PT_OK : ctx->fail(rc, err);
 }
 

@@ -39,6 +39,8 @@ struct AccelScratch {
     void* ploc_scan_temp = nullptr; size_t ploc_scan_bytes = 0;
     size_t capacity = 0;
     std::string why;                         // what a failed build ran into (the hipError_t alone says "unknown error")
+    uint32_t fallbacks = 0;                  // builds in which the PLOC clustering gave up and the radix tree took over
+    std::string fallback_why;                // ... and why, the last time
 };
 void accel_scratch_free(AccelScratch& s);
 // Builds the 4-wide BVH (<= n_tris nodes), the sorted intersection packets and their shading packets (n_tris each).
@@ -92,7 +94,9 @@ void launch_skin(const SkinArgs& a, bool use_mfma, hipStream_t stream);
 void launch_tonemap(const float4* in, uint32_t w, uint32_t h, const pt_tonemap_config& cfg, float* out_rgb, uint32_t* out_rgba8, hipStream_t stream);
 
 // ---- pt_wavefront.hip / pt_kernel.hip ---------------------------------------------------------
-int traversal_stack_capacity();          // entries a ray's traversal stack holds (LDS part + scratch spill)
+size_t traversal_grid_lanes(int stage_blocks);   // lanes of the widest traversal launch of a wavefront trace with that many stage workgroups
+constexpr uint32_t kDeepStackMax = 1024;      // most stack entries a tree may ask for (64 on chip + a deep stack in memory); a clustered tree beyond it is rebuilt as a radix tree
+int traversal_stack_capacity();          // entries a ray's traversal stack holds on chip (LDS part + scratch spill); deeper trees get SceneRec::deep_stack
 // Optional per-stage timing of one wavefront launch (pt_enable_stage_timing): an event after every stage launch.
 enum { STAGE_GENERATE = 0, STAGE_TRACE = 1, STAGE_SHADE = 2, STAGE_SHADOW = 3, STAGE_RESOLVE = 4, STAGE_COUNT = 5 };
 struct StageTimers {
@@ -111,7 +115,10 @@ uint32_t tiles_of_rank(uint32_t w, uint32_t h, uint32_t rank, uint32_t world);
 hipError_t tiles_pack(const void* image, uint32_t w, uint32_t h, uint32_t rank, uint32_t world, void* packed, hipStream_t stream);
 hipError_t tiles_unpack(const void* packed, uint32_t w, uint32_t h, uint32_t rank, uint32_t world, void* image, hipStream_t stream);
 int exchange_unique_id(void* out128, std::string& err);
+int exchange_probe(std::string& err);
 int exchange_create(ExchangeState** out, int rank, int world, const void* id128, std::string& err);
+int exchange_create_loopback(ExchangeState** out, int rank, int world, uint64_t group, int device, std::string& err);
+const char* exchange_transport_name(const ExchangeState* x);
 int exchange_frame(ExchangeState* x, const void* local, void* frame, uint32_t w, uint32_t h, int mode, int dst, hipStream_t stream, std::string& err);
 void exchange_free(ExchangeState* x);
 

@@ -101,6 +101,7 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(SceneRec sc, FrameConsta
     }
     if (in_image) write_pixel(fc, fc.accumulated_frames, output, px, py, L);
     flush_counters(counters, threadIdx.x & 63, n_primary, n_bounce, n_shadow, n_hits, st);
+    if (st.deep) atomicAdd(&counters->deep_pushes, (unsigned long long)st.deep);
 }
 
 template __global__ void pt_megakernel<false>(SceneRec, FrameConstants, float4*, Counters*);

@@ -43,7 +43,7 @@ enum : uint32_t { RF_CULL_BACK = 1, RF_CULL_FRONT = 2, RF_FORCE_NON_OPAQUE = 4, 
 struct Ray { vec3 o; float tmin; vec3 d; float tmax; };
 struct HitRec { float t, u, v; int tri; bool front; };
 
-struct LaneStats { unsigned nodes, tris, taps, overflow; };
+struct LaneStats { unsigned nodes, tris, taps, overflow, deep; };
 
 // Alpha of a candidate hit: AnyHit / ShadowAnyHit (PathTracer.lib.hlsl:1010-1035, 1053-1079).
 PT_DEV void candidate_alpha(const SceneRec& sc, uint32_t inst, int tri, float u, float v, unsigned& taps, float& base_alpha,
@@ -71,7 +71,13 @@ struct Trav {
 
 PT_DEV void trav_init(Trav& t, const SceneRec& sc, const Ray& r, uint32_t rf, uint32_t mask, int mode, float transmission0) {
     t.o = r.o; t.d = r.d; t.tmin = r.tmin; t.tmax = r.tmax;
-    t.inv = v3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);           // the compiler's full division: a subnormal direction component must give infinity, not NaN
+    // 1 / direction by the compiler's full division (a subnormal component must not give NaN), then CLAMPED to +-1e30: the slab test below is
+    // plane * inv - origin * inv, and with inv = inf (a direction component that is exactly zero: an orthographic camera looking along a
+    // world axis, a mirror bounce off an axis-aligned wall) both products are infinities whose difference is NaN -- the ray then missed every
+    // box whose slab it was INSIDE of, i.e. the whole scene.  A huge finite inv keeps the products finite: (plane - origin) * 1e30 is far
+    // beyond any ray interval with the sign it should have, for every plane farther than |origin| * 2^-24 from the origin's coordinate.
+    const float kInvMax = 1.0e30f;
+    t.inv = v3(clampf(1.0f / r.d.x, -kInvMax, kInvMax), clampf(1.0f / r.d.y, -kInvMax, kInvMax), clampf(1.0f / r.d.z, -kInvMax, kInvMax));
     t.ood = v3(r.o.x * t.inv.x, r.o.y * t.inv.y, r.o.z * t.inv.z);
     t.rf = rf; t.mask = mask; t.mode = mode;
     t.all_candidates = (mode == 1) && (rf & RF_FORCE_NON_OPAQUE);
@@ -85,20 +91,26 @@ PT_DEV void trav_init(Trav& t, const SceneRec& sc, const Ray& r, uint32_t rf, ui
 // FAST: the caller has established (wave-uniformly) that no active lane can leave the LDS part of the stack in this step, so
 // a push is one predicated ds_write instead of a three-way LDS / scratch / overflow branch nest.
 template <bool FAST = false>
-PT_DEV void trav_push(Trav& t, int* lds_stack, int* spill, int ref, LaneStats& st) {
+PT_DEV void trav_push(Trav& t, const SceneRec& sc, int* lds_stack, int* spill, int ref, LaneStats& st) {
     if (FAST) { lds_stack[t.sp * kBlock] = ref; t.sp++; return; }
     if (t.sp < kStackLds) lds_stack[t.sp * kBlock] = ref;
     else if (t.sp < kStackLds + kStackSpill) spill[t.sp - kStackLds] = ref;
+    else if (sc.deep_entries != 0 && t.sp < kStackLds + kStackSpill + (int)sc.deep_entries) {     // (scalar test first: no deep stack in ordinary scenes)
+        sc.deep_stack[(size_t)(t.sp - (kStackLds + kStackSpill)) * sc.deep_lanes + blockIdx.x * kBlock + threadIdx.x] = ref;
+        st.deep++;
+    }
     else st.overflow++;
-    if (t.sp < kStackLds + kStackSpill) t.sp++;
+    if (t.sp < kStackLds + kStackSpill + (int)sc.deep_entries) t.sp++;
 }
-PT_DEV void trav_pop(Trav& t, const int* lds_stack, const int* spill) {
+PT_DEV void trav_pop(Trav& t, const SceneRec& sc, const int* lds_stack, const int* spill) {
     if (t.sp == 0) { t.cur = kTravDone; return; }
     t.sp--;
     // always a ds_read (a select between the LDS and the scratch address would make this a flat_load on every pop)
     int v = lds_stack[min(t.sp, kStackLds - 1) * kBlock];
     asm volatile("" : "+v"(v));                            // keep the two loads apart (the optimiser would re-merge them)
-    if (t.sp >= kStackLds) v = spill[t.sp - kStackLds];
+    if (t.sp >= kStackLds) v = spill[min(t.sp, kStackLds + kStackSpill - 1) - kStackLds];
+    if (sc.deep_entries != 0 && t.sp >= kStackLds + kStackSpill)
+        v = sc.deep_stack[(size_t)(t.sp - (kStackLds + kStackSpill)) * sc.deep_lanes + blockIdx.x * kBlock + threadIdx.x];
     t.cur = v;
 }
 
@@ -146,10 +158,10 @@ PT_DEV void trav_node_step(Trav& t, const SceneRec& sc, int* lds_stack, int* spi
         int next = kTravDone;
 #define PT_PUSH_UNORDERED(F)                                                                                                        \
         _Pragma("unroll") for (int k = 0; k < 8; k++)                                                                               \
-            if (e[k] != ~0ull) { if (next != kTravDone) trav_push<F>(t, lds_stack, spill, (int)(uint32_t)e[k], st); else next = (int)(uint32_t)e[k]; }
+            if (e[k] != ~0ull) { if (next != kTravDone) trav_push<F>(t, sc, lds_stack, spill, (int)(uint32_t)e[k], st); else next = (int)(uint32_t)e[k]; }
         if (shallow) { PT_PUSH_UNORDERED(true) } else { PT_PUSH_UNORDERED(false) }
 #undef PT_PUSH_UNORDERED
-        if (next != kTravDone) t.cur = next; else trav_pop(t, lds_stack, spill);
+        if (next != kTravDone) t.cur = next; else trav_pop(t, sc, lds_stack, spill);
         return;
     }
     // nearest child first, the other hit children pushed as they come (their order only affects how soon a later box is culled)
@@ -158,11 +170,11 @@ PT_DEV void trav_node_step(Trav& t, const SceneRec& sc, int* lds_stack, int* spi
     for (int k = 1; k < 8; k++) best = e[k] < best ? e[k] : best;
     if (best != ~0ull) {
 #define PT_PUSH_REST(F)                                                                                                             \
-        _Pragma("unroll") for (int k = 0; k < 8; k++) if (e[k] != ~0ull && e[k] != best) trav_push<F>(t, lds_stack, spill, (int)(uint32_t)e[k], st);
+        _Pragma("unroll") for (int k = 0; k < 8; k++) if (e[k] != ~0ull && e[k] != best) trav_push<F>(t, sc, lds_stack, spill, (int)(uint32_t)e[k], st);
         if (shallow) { PT_PUSH_REST(true) } else { PT_PUSH_REST(false) }
 #undef PT_PUSH_REST
         t.cur = (int)(uint32_t)best;
-    } else trav_pop(t, lds_stack, spill);
+    } else trav_pop(t, sc, lds_stack, spill);
 }
 #else
 // One inner-node step: t.cur >= 0 on entry; on exit t.cur is the nearest hit child, or the popped entry, or kTravDone.
@@ -211,19 +223,19 @@ PT_DEV void trav_node_step(Trav& t, const SceneRec& sc, int* lds_stack, int* spi
         // pushed last-slot-first so that they pop in slot order too
         if (key[3] != 0xffffffffu) next = c3;
 #define PT_PUSH_UNORDERED(F)                                                                                                        \
-        if (key[2] != 0xffffffffu) { if (next != kTravDone) trav_push<F>(t, lds_stack, spill, next, st); next = c2; }               \
-        if (key[1] != 0xffffffffu) { if (next != kTravDone) trav_push<F>(t, lds_stack, spill, next, st); next = c1; }               \
-        if (key[0] != 0xffffffffu) { if (next != kTravDone) trav_push<F>(t, lds_stack, spill, next, st); next = c0; }
+        if (key[2] != 0xffffffffu) { if (next != kTravDone) trav_push<F>(t, sc, lds_stack, spill, next, st); next = c2; }               \
+        if (key[1] != 0xffffffffu) { if (next != kTravDone) trav_push<F>(t, sc, lds_stack, spill, next, st); next = c1; }               \
+        if (key[0] != 0xffffffffu) { if (next != kTravDone) trav_push<F>(t, sc, lds_stack, spill, next, st); next = c0; }
 #else
         if (key[0] != 0xffffffffu) next = c0;
 #define PT_PUSH_UNORDERED(F)                                                                                                        \
-        if (key[1] != 0xffffffffu) { if (next != kTravDone) trav_push<F>(t, lds_stack, spill, c1, st); else next = c1; }           \
-        if (key[2] != 0xffffffffu) { if (next != kTravDone) trav_push<F>(t, lds_stack, spill, c2, st); else next = c2; }           \
-        if (key[3] != 0xffffffffu) { if (next != kTravDone) trav_push<F>(t, lds_stack, spill, c3, st); else next = c3; }
+        if (key[1] != 0xffffffffu) { if (next != kTravDone) trav_push<F>(t, sc, lds_stack, spill, c1, st); else next = c1; }           \
+        if (key[2] != 0xffffffffu) { if (next != kTravDone) trav_push<F>(t, sc, lds_stack, spill, c2, st); else next = c2; }           \
+        if (key[3] != 0xffffffffu) { if (next != kTravDone) trav_push<F>(t, sc, lds_stack, spill, c3, st); else next = c3; }
 #endif
         if (shallow) { PT_PUSH_UNORDERED(true) } else { PT_PUSH_UNORDERED(false) }
 #undef PT_PUSH_UNORDERED
-        if (next != kTravDone) t.cur = next; else trav_pop(t, lds_stack, spill);
+        if (next != kTravDone) t.cur = next; else trav_pop(t, sc, lds_stack, spill);
         return;
     }
     // sort the 4 keys ascending (tn >= 0, so its bit pattern orders like the float); misses sink to the end
@@ -231,13 +243,13 @@ PT_DEV void trav_node_step(Trav& t, const SceneRec& sc, int* lds_stack, int* spi
     auto child_of = [&](uint32_t k) { uint32_t s = k & 3u; return s == 0 ? c0 : (s == 1 ? c1 : (s == 2 ? c2 : c3)); };
     if (key[0] != 0xffffffffu) {
 #define PT_PUSH_ORDERED(F)                                                                                                          \
-        if (key[3] != 0xffffffffu) trav_push<F>(t, lds_stack, spill, child_of(key[3]), st);                                         \
-        if (key[2] != 0xffffffffu) trav_push<F>(t, lds_stack, spill, child_of(key[2]), st);                                         \
-        if (key[1] != 0xffffffffu) trav_push<F>(t, lds_stack, spill, child_of(key[1]), st);
+        if (key[3] != 0xffffffffu) trav_push<F>(t, sc, lds_stack, spill, child_of(key[3]), st);                                         \
+        if (key[2] != 0xffffffffu) trav_push<F>(t, sc, lds_stack, spill, child_of(key[2]), st);                                         \
+        if (key[1] != 0xffffffffu) trav_push<F>(t, sc, lds_stack, spill, child_of(key[1]), st);
         if (shallow) { PT_PUSH_ORDERED(true) } else { PT_PUSH_ORDERED(false) }
 #undef PT_PUSH_ORDERED
         t.cur = child_of(key[0]);
-    } else trav_pop(t, lds_stack, spill);
+    } else trav_pop(t, sc, lds_stack, spill);
 }
 #endif
 
@@ -299,7 +311,7 @@ PT_DEV void trav_leaf_step(Trav& t, const SceneRec& sc, const int* lds_stack, co
 #if PT_LEAF_SINGLE
     else if (count > 1) t.cur = ~(int)(((uint32_t)(first + 1) & kLeafFirstMask) | ((uint32_t)(count - 2) << 28));
 #endif
-    else trav_pop(t, lds_stack, spill);
+    else trav_pop(t, sc, lds_stack, spill);
 }
 
 // mode 0: closest hit (hit group 0).  mode 1: occlusion / shadow (hit group 1), `transmission` is the ShadowPayload.

@@ -190,6 +190,11 @@ struct SceneRec {
     const float2* tangent_lut;  // 1024 x (sin, cos) of the packed tangent angle (pt_shading.h tangent_sincos_compute)
     EnvRec env;
     int32_t has_env;
+    // Deep traversal stack, only for trees whose build-time bound exceeds the 64 entries a lane holds in LDS + scratch (long chains of
+    // coincident centroids): entry k >= 64 of lane g lives at deep_stack[(k - 64) * deep_lanes + g], g = blockIdx.x * 256 + threadIdx.x.
+    // deep_entries == 0 (every ordinary scene): one scalar test per pop / slow push, nothing else.
+    int32_t* deep_stack;
+    uint32_t deep_entries, deep_lanes;
 };
 
 // SceneConstants (PathTracer.lib.hlsl:10-30) plus the tile shard of this rank.
@@ -231,6 +236,7 @@ struct FrameConstants {
 struct Counters {
     unsigned long long rays_primary, rays_bounce, rays_shadow, nodes, tris, hits, taps, stack_overflow;
     unsigned long long nodes_shadow, tris_shadow;      // the occlusion stage's share (wavefront mode; the megakernel books everything above)
+    unsigned long long deep_pushes;                    // stack entries written beyond the 64 on-chip ones (SceneRec::deep_stack)
 };
 
 }  // namespace pt

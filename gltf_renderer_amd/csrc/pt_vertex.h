@@ -278,6 +278,11 @@ PT_DEV bool slot_pixel(const FrameConstants& fc, uint32_t slot, uint32_t& px, ui
 
 // wave64 reduction of the per-lane tallies, one atomic per wave per counter
 // occlusion: the node / triangle tallies go to Counters::nodes_shadow / tris_shadow (slots 8, 9) instead of nodes / tris (3, 4)
+// the two tallies every build keeps (not only the counting instantiations): pushes a full stack dropped, pushes that went to the deep stack
+PT_DEV void flush_rare(Counters* __restrict__ counters, const LaneStats& st) {
+    if (st.overflow) atomicAdd(&counters->stack_overflow, (unsigned long long)st.overflow);
+    if (st.deep) atomicAdd(&counters->deep_pushes, (unsigned long long)st.deep);
+}
 PT_DEV void flush_counters(Counters* __restrict__ counters, uint32_t lane, unsigned n_primary, unsigned n_bounce, unsigned n_shadow, unsigned n_hits,
                            const LaneStats& st, bool occlusion = false) {
     unsigned vals[8] = {n_primary, n_bounce, n_shadow, st.nodes, st.tris, n_hits, st.taps, st.overflow};

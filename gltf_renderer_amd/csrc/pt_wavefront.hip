@@ -364,8 +364,8 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_trace(SceneRec sc
     if (sv.member == 0 && threadIdx.x == 0) { wf.cnt[cur ^ 1][sv.shard * kCounterStride] = 0; wf.cnt[shadow_counter(bounce)][sv.shard * kCounterStride] = 0; wf.cnt[6][sv.shard * kCounterStride] = 0; }
     LaneStats st = {0, 0, 0, 0};
     trace_persistent<COUNT, 0>(sc, wf, s_stack + threadIdx.x, sv, cur, rf, rmask, 0, st);
-    if (COUNT) flush_counters(counters, threadIdx.x & 63, 0, 0, 0, 0, st);
-    else if (st.overflow) atomicAdd(&counters->stack_overflow, (unsigned long long)st.overflow);
+    if (COUNT) { flush_counters(counters, threadIdx.x & 63, 0, 0, 0, 0, st); if (st.deep) atomicAdd(&counters->deep_pushes, (unsigned long long)st.deep); }
+    else if (st.overflow | st.deep) flush_rare(counters, st);
 }
 
 // Fused traversal stage: the occlusion rays of bounce `bounce` AND the closest-hit rays of bounce + 1.  Both were produced by the
@@ -384,8 +384,10 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_traverse(SceneRec
     LaneStats st_shadow = {0, 0, 0, 0}, st = {0, 0, 0, 0};
     trace_persistent<COUNT, 1>(sc, wf, s_stack + threadIdx.x, sv, shadow_counter(bounce), 0, 0xff, flags, st_shadow);
     trace_persistent<COUNT, 0>(sc, wf, s_stack + threadIdx.x, sv, nxt, rf, rmask, 0, st);
-    if (COUNT) { flush_counters(counters, threadIdx.x & 63, 0, 0, 0, 0, st_shadow, true); flush_counters(counters, threadIdx.x & 63, 0, 0, 0, 0, st); }
-    else if (st.overflow + st_shadow.overflow) atomicAdd(&counters->stack_overflow, (unsigned long long)(st.overflow + st_shadow.overflow));
+    if (COUNT) {
+        flush_counters(counters, threadIdx.x & 63, 0, 0, 0, 0, st_shadow, true); flush_counters(counters, threadIdx.x & 63, 0, 0, 0, 0, st);
+        if (st.deep | st_shadow.deep) atomicAdd(&counters->deep_pushes, (unsigned long long)st.deep + st_shadow.deep);
+    } else if (st.overflow | st_shadow.overflow | st.deep | st_shadow.deep) { flush_rare(counters, st); flush_rare(counters, st_shadow); }
 }
 
 // The reference multiplies the light colour by the shadow transmission BEFORE `if (any(color > 0))` and never evaluates
@@ -543,8 +545,8 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_shadow(SceneRec s
     const ShardView sv = shard_view(wf);
     LaneStats st = {0, 0, 0, 0};
     trace_persistent<COUNT, 1>(sc, wf, s_stack + threadIdx.x, sv, shadow_counter(bounce), 0, 0xff, flags, st);
-    if (COUNT) flush_counters(counters, threadIdx.x & 63, 0, 0, 0, 0, st, true);
-    else if (st.overflow) atomicAdd(&counters->stack_overflow, (unsigned long long)st.overflow);
+    if (COUNT) { flush_counters(counters, threadIdx.x & 63, 0, 0, 0, 0, st, true); if (st.deep) atomicAdd(&counters->deep_pushes, (unsigned long long)st.deep); }
+    else if (st.overflow | st.deep) flush_rare(counters, st);
 }
 
 __global__ __launch_bounds__(kBlock) void k_wf_resolve(FrameConstants fc, WfBuffers wf, float4* __restrict__ output) {
@@ -632,6 +634,7 @@ static WfBuffers carve(void* base, const FrameConstants& fc, int stage_blocks) {
 }
 
 int traversal_stack_capacity() { return kStackLds + kStackSpill; }
+size_t traversal_grid_lanes(int stage_blocks) { return (size_t)kShards * blocks_per_shard_for(stage_blocks) * kBlock; }
 
 hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4* output, Counters* counters, bool count, void* workspace,
                             int stage_blocks, StageTimers* timers, hipStream_t stream) {

@@ -22,7 +22,7 @@ EXPORTS = ["pt_abi_version", "pt_create", "pt_destroy", "pt_last_error", "pt_buf
            "pt_get_stats", "pt_reset_stats", "pt_readback", "pt_tonemap",
            # ABI 2
            "pt_buffer_destroy", "pt_texture_destroy", "pt_env_destroy", "pt_accel_request_rebuild", "pt_set_accel_builder", "pt_enable_stage_timing",
-           "pt_exchange_unique_id", "pt_exchange_create", "pt_exchange_frame", "pt_exchange_destroy",
+           "pt_exchange_unique_id", "pt_exchange_probe", "pt_exchange_create", "pt_exchange_create_loopback", "pt_exchange_frame", "pt_exchange_destroy",
            "pt_tiles_packed_bytes", "pt_tiles_pack", "pt_tiles_unpack"]
 
 
@@ -87,6 +87,8 @@ def load_library():
     L.pt_enable_stage_timing.argtypes = [vp, ci]
     L.pt_exchange_unique_id.argtypes = [vp]
     L.pt_exchange_create.argtypes = [vp, ci, ci, vp]
+    L.pt_exchange_probe.argtypes = []
+    L.pt_exchange_create_loopback.argtypes = [vp, ci, ci, C.c_uint64]
     L.pt_exchange_frame.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, ci, ci]
     L.pt_exchange_destroy.argtypes = [vp]
     L.pt_tiles_packed_bytes.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
@@ -246,6 +248,11 @@ class Renderer:
         self._check(self.L.pt_enable_stage_timing(self.h, int(bool(on))))
 
     # ---- multi-GPU exchange (RCCL inside libmipt.so; the unique id travels by whatever transport the host has)
+    @staticmethod
+    def exchange_probe():
+        """True if RCCL can be loaded in this process (no GPU call): ranks agree on this before any enters the collective create."""
+        return load_library().pt_exchange_probe() == 0
+
     def exchange_unique_id(self):
         buf = (C.c_ubyte * abi.EXCHANGE_ID_BYTES)()
         rc = self.L.pt_exchange_unique_id(buf)
@@ -256,6 +263,10 @@ class Renderer:
     def exchange_create(self, rank, world, unique_id=None):
         buf = None if unique_id is None else (C.c_ubyte * abi.EXCHANGE_ID_BYTES).from_buffer_copy(unique_id)
         self._check(self.L.pt_exchange_create(self.h, rank, world, buf))
+
+    def exchange_create_loopback(self, rank, world, group):
+        """N contexts of this process exchange by device-to-device copies (no RCCL); call exchange_frame on the root last."""
+        self._check(self.L.pt_exchange_create_loopback(self.h, rank, world, C.c_uint64(group)))
 
     def exchange_frame(self, local, frame=None, mode=abi.EXCHANGE_GATHER, dst=0):
         """local: this rank's accumulation image (H, W, 4) CUDA tensor, only read.  frame: where the root assembles the frame

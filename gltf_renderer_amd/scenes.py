@@ -626,11 +626,69 @@ def bones_for_pose(skin, node_global, joint_globals):
     return out
 
 
+MORPH_TARGET_KINDS = ("position+normal+tangent", "position", "position+normal", "normal+tangent", "position+normal+tangent", "position")
+
+
+def add_morph_targets(s, skin_index=0, seed=11):
+    """Six morph targets for the figure's primitive, as Gltf::CreateMorphTarget uploads them (Gltf.cpp:323-367): a float3
+    position-delta stream when the target has POSITION, and -- when it has NORMAL -- a 10-10-10-2 stream made by
+    EncodeTangentSpace(normal delta, tangent delta) (with TANGENT) or EncodeNormal(normal delta) (without).  One of each kind
+    (MORPH_TARGET_KINDS), so that Skin.cs.hlsl:70-88's two descriptor tests are taken both ways.  Records go to
+    s.skins[i]["targets"] = [{"position": buffer or -1, "tangent_space": buffer or -1, "sources": {...}}]."""
+    sk = s.skins[skin_index]
+    mesh = sk["mesh"]
+    nv = mesh.num_vertices
+    rng = np.random.default_rng(seed)
+    P = mesh.positions.astype(np.float64)
+    targets = []
+    for k, kind in enumerate(MORPH_TARGET_KINDS):
+        src, rec = {}, {"position": -1, "tangent_space": -1}
+        if "position" in kind:
+            ph = rng.uniform(0, 2 * math.pi, 3)
+            amp = 0.04 + 0.02 * k
+            dp = amp * np.stack([np.sin(7.0 * P[:, 2] + ph[0]), np.cos(5.0 * P[:, 0] + ph[1]), np.sin(9.0 * P[:, 1] + 3.0 * P[:, 2] + ph[2])], axis=1)
+            src["POSITION"] = dp.astype(np.float32)
+            rec["position"] = s.add_buffer(src["POSITION"], abi.FORMAT_R32G32B32_FLOAT)
+        if "normal" in kind:
+            dn = rng.normal(0, 0.3, (nv, 3)) + np.array([0.2, -0.1, 0.3])
+            src["NORMAL"] = dn.astype(np.float32)
+            if "tangent" in kind:
+                dt = rng.normal(0, 0.3, (nv, 3)) + np.array([-0.3, 0.2, 0.1])
+                # a glTF morph TANGENT is a VEC3 delta; upstream iterates it as 4 floats, the missing w filled with 1 (TinyGltfTools.h:217-219)
+                src["TANGENT"] = np.concatenate([dt, np.ones((nv, 1))], axis=1).astype(np.float32)
+                packed = meshgen.encode_tangent_space(src["NORMAL"], src["TANGENT"])
+            else:
+                packed = meshgen.encode_normal(src["NORMAL"])
+            rec["tangent_space"] = s.add_buffer(packed, abi.FORMAT_R10G10B10A2_UNORM)
+        rec["sources"] = src
+        targets.append(rec)
+    sk["targets"] = targets
+    return targets
+
+
+def pick_morph_targets(current_weights, max_targets=abi.MAX_SIMULTANEOUS_MORPH_TARGETS):
+    """Renderer::PerformSkinning's choice (Renderer.cpp:425-443): walk the node's weights in order, keep those > 0; once four are
+    held, a later weight replaces the FIRST smallest held one if it is larger.  Returns [(target index, weight)] in slot order."""
+    w, which = [], []
+    for j, cw in enumerate(current_weights):
+        cw = float(np.float32(cw))
+        if not cw > 0.0:
+            continue
+        if len(w) < max_targets:
+            w.append(cw); which.append(j)
+        else:
+            mi = int(np.argmin(w))                       # std::min_element: the first of equal minima
+            if w[mi] < cw:
+                w[mi] = cw; which[mi] = j
+    return list(zip(which, w))
+
+
 class SkinBinding:
     """The per-frame dynamic-mesh step of Renderer::DrawFrame for one skinned instance (Renderer.cpp:399-457,
-    Pathtracer.cpp:235-240): output streams, GpuSkin::Run parameters, and the instance table re-pointed at them."""
+    Pathtracer.cpp:235-240): output streams, GpuSkin::Run parameters, and the instance table re-pointed at them.
+    morph = [(target index, weight)] (<= 4, e.g. from pick_morph_targets) binds morph targets made by add_morph_targets."""
 
-    def __init__(self, backend, scene, handles, skin_index=0, use_mfma=1):
+    def __init__(self, backend, scene, handles, skin_index=0, use_mfma=1, morph=None):
         sk = scene.skins[skin_index]
         mesh = sk["mesh"]
         self.backend, self.skin = backend, sk
@@ -648,6 +706,12 @@ class SkinBinding:
         for i in range(4):
             p.morph_position[i] = -1
             p.morph_tangent_space[i] = -1
+        for i, (ti, w) in enumerate(morph or []):
+            t = sk["targets"][ti]
+            p.morph_weights[i] = w
+            p.morph_position[i] = handles["buffers"][t["position"]] if t["position"] != -1 else -1
+            p.morph_tangent_space[i] = handles["buffers"][t["tangent_space"]] if t["tangent_space"] != -1 else -1
+            p.num_of_morph_targets = i + 1
         p.use_mfma = int(use_mfma)
         self.params = p
         inst = [abi.PtInstanceDesc.from_buffer_copy(bytes(d)) for d in handles["instances"]]
@@ -656,6 +720,7 @@ class SkinBinding:
         self.instances = inst
         backend.set_instances(inst)
 
-    def pose(self, t):
-        """Skin the mesh to the walk-cycle pose at time t (seconds); the caller rebuilds the acceleration structure."""
-        self.backend.skin_run(self.params, bones_for_pose(self.skin, np.eye(4), skinned_figure_pose(t)))
+    def pose(self, t, bones=True):
+        """Skin the mesh to the walk-cycle pose at time t (seconds); the caller rebuilds the acceleration structure.
+        bones=False: a morphed, unskinned node -- GpuSkin::Run is handed no bone buffer (Renderer.cpp:449, quirk q19)."""
+        self.backend.skin_run(self.params, bones_for_pose(self.skin, np.eye(4), skinned_figure_pose(t)) if bones else None)

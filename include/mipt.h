@@ -321,6 +321,11 @@ typedef struct pt_stats {
     uint32_t bvh_stack_need;    /* most traversal-stack entries any ray can hold in the current tree (build-time bound) */
     uint32_t accel_builds;      /* full builds / refits since pt_create */
     uint32_t accel_refits;
+    uint32_t bvh_stack_capacity;       /* entries a ray's traversal stack holds for the current tree: 64 on chip, more (in memory) when
+                                          bvh_stack_need asks for it -- a deep tree is never refused and never drops geometry */
+    uint32_t accel_builder_fallbacks;  /* builds in which the clustering builder gave up (or made a tree too deep) and the radix
+                                          tree over the same Morton order took over */
+    uint64_t deep_stack_pushes;        /* stack entries rays wrote beyond the 64 on-chip ones since pt_reset_stats (0 for ordinary scenes) */
 } pt_stats;
 
 typedef struct pt_ctx pt_ctx;
@@ -445,7 +450,16 @@ int pt_tonemap(pt_ctx* ctx, const pt_tonemap_config* config, const void* device_
 #define PT_EXCHANGE_ID_BYTES 128
 enum { PT_EXCHANGE_GATHER = 0, PT_EXCHANGE_REDUCE = 1 };
 int pt_exchange_unique_id(void* id_out);
+/* PT_OK if RCCL can be loaded in this process, PT_ERR_NOT_READY otherwise.  No GPU call, no communicator: a job lets every rank
+ * probe and agree on the outcome BEFORE any rank enters pt_exchange_unique_id / pt_exchange_create (ncclCommInitRank is collective:
+ * a rank that cannot load RCCL would leave the others waiting in it). */
+int pt_exchange_probe(void);
 int pt_exchange_create(pt_ctx* ctx, int rank, int world, const void* unique_id);
+/* The same exchange for N contexts of ONE process (on one GPU or several): no RCCL, the transfers are stream-ordered
+ * device-to-device copies between the contexts that joined the same `group` (any host-chosen number).  Transfers are posted, not
+ * blocking: call pt_exchange_frame on the root AFTER the other ranks, every frame (PT_ERR_NOT_READY otherwise).  This is also how
+ * the N > 1 logic of the exchange is tested on a one-GPU box. */
+int pt_exchange_create_loopback(pt_ctx* ctx, int rank, int world, uint64_t group);
 int pt_exchange_frame(pt_ctx* ctx, const void* local_image, void* frame, uint32_t width, uint32_t height, int mode, int dst_rank);
 int pt_exchange_destroy(pt_ctx* ctx);
 /* The transport-free halves of the gather, for hosts with their own transport (and the tests): a rank's tiles in slot order,

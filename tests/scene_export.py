@@ -135,9 +135,11 @@ def scene_to_builder(scene, embed="view"):
     return b
 
 
-def skinned_figure_to_builder(scene, seconds=2.0, rate=30):
+def skinned_figure_to_builder(scene, seconds=2.0, rate=30, morph_weights=None):
     """Config 5 as a glTF file: the capsule figure with its 19-joint skin and the walk cycle as LINEAR rotation / translation
-    channels sampled at `rate` Hz (scenes.skinned_figure_pose keyframes), plus the static ground plane, lights and materials."""
+    channels sampled at `rate` Hz (scenes.skinned_figure_pose keyframes), plus the static ground plane, lights and materials.
+    With scenes.add_morph_targets records on the skin, the primitive also gets its `targets` (POSITION / NORMAL / TANGENT VEC3
+    deltas) and the figure's node `weights` = morph_weights."""
     from gltf_renderer_amd import scenes
     sk = scene.skins[0]
     b = scene_to_builder(scene)
@@ -148,6 +150,11 @@ def skinned_figure_to_builder(scene, seconds=2.0, rate=30):
     prim = fig_mesh["primitives"][0]
     prim["attributes"]["JOINTS_0"] = b.accessor(np.asarray(mesh.joints, np.uint16))
     prim["attributes"]["WEIGHTS_0"] = b.accessor(np.asarray(mesh.weights, np.float32))
+    if sk.get("targets"):
+        prim["targets"] = [{k: b.accessor(np.ascontiguousarray(v[:, :3], np.float32)) for k, v in t["sources"].items()} for t in sk["targets"]]
+        fig_mesh["weights"] = [0.0] * len(sk["targets"])
+        if morph_weights is not None:
+            b.j["nodes"][fig_node]["weights"] = [float(w) for w in morph_weights]
     # joints live directly in the Z-up world of the generator: parent them to a node that undoes the loader's Y-up root
     joint_nodes = []
     for j in range(19):

@@ -20,7 +20,7 @@ def _worker(rank, world, port, tmp):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gltf_renderer_amd import abi, scenes
-    from gltf_renderer_amd.sharding import my_tile_count
+    from tests.sharding_double import my_tile_count
     from oracle import pyoracle
     s = scenes.test_scene(40, 16)
     st = abi.PtSettings.from_buffer_copy(bytes(s.settings)); st.flags &= ~abi.FLAG_ACCUMULATE
@@ -30,7 +30,7 @@ def _worker(rank, world, port, tmp):
     touched = int((img[..., 3] != 0).sum())
     t = torch.from_numpy(img)
     # the point-to-point form of the exchange on a copy whose foreign pixels hold garbage (it must not read them) ...
-    from gltf_renderer_amd.sharding import TileExchange
+    from tests.sharding_double import TileExchange
     g = torch.from_numpy(np.where(img[..., 3:4] != 0, img, np.float32(123.0)).astype(np.float32))
     xch = TileExchange(s.width, s.height, world, "cpu")
     xch.gather_frame(g, rank)
@@ -89,7 +89,7 @@ def test_two_rank_tile_sharding_equals_single_rank(tmp_path, oracle_lib):
 
 
 def test_tile_partition_is_exact():
-    from gltf_renderer_amd.sharding import my_tile_count, tile_owner
+    from tests.sharding_double import my_tile_count, tile_owner
     for (w, h) in ((1920, 1080), (3840, 2160), (50, 17), (16, 16), (1, 1)):
         tiles = ((w + 15) // 16) * ((h + 15) // 16)
         for n in (1, 2, 3, 4, 8):
@@ -98,3 +98,18 @@ def test_tile_partition_is_exact():
             assert all(0 <= o < n for o in owners)
             for r in range(n):
                 assert owners.count(r) == my_tile_count(w, h, r, n)
+
+
+def test_bench_refuses_a_rank_count_it_cannot_honour():
+    """`python bench.py --gpus N` started plainly launches its own ranks -- and exits non-zero, before any GPU call, when the node has
+    fewer than N devices; under a launcher whose WORLD_SIZE differs from --gpus it refuses too: `n_gpus` of the line is always the
+    number of ranks that rendered (it used to render on one GPU and print n_gpus 1)."""
+    import subprocess
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two devices present: the launch would succeed")
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "device(s) visible" in out.stderr and not out.stdout.strip()
+    out = subprocess.run([sys.executable, bench, "--gpus", "1"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE 2" in out.stderr and not out.stdout.strip()

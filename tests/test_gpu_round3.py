@@ -1,0 +1,429 @@
+"""GPU tests added in round 3 (run with -m gpu on an MI355X; everything goes through the C-ABI of libmipt.so):
+
+  * morph targets of GpuSkin::Run (Skin.cs.hlsl:70-88): 1-4 targets, position-only / with tangent space, skinned + morphed, morph-only
+    with no bone buffer (quirk q19, GpuSkin.cpp:94), both k_skin and k_skin_mfma, against the oracle and against a float64 restatement;
+    the four-largest-positive-weights pick of Renderer::PerformSkinning (Renderer.cpp:425-443) through the glTF loader + gs_frame;
+  * one exact-BASELINE-size single-sample frame per config against the oracle (configs 2-5 at the resolution, texture sizes and bounce
+    counts BASELINE.json names): equal ray counts, per-pixel-sample differences counted, the north_star contract (1e-3 relative L2 after
+    tone mapping) asserted and the measured figure printed.
+
+PARITY UNPINNED vs real DXR output: the oracle is this repository's CPU restatement of the reference's HLSL."""
+import numpy as np
+import pytest
+
+from gltf_renderer_amd import abi, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def copy_settings(s):
+    return abi.PtSettings.from_buffer_copy(bytes(s))
+
+
+@pytest.fixture(scope="module")
+def R():
+    from gltf_renderer_amd.renderer import Renderer
+    return Renderer
+
+
+def rel_l2(a, b):
+    a = a.astype(np.float64); b = b.astype(np.float64)
+    fa, fb = np.isfinite(a), np.isfinite(b)
+    assert (fa != fb).mean() < 1e-3, float((fa != fb).mean())
+    ok = fa & fb
+    return float(np.sqrt(((a[ok] - b[ok]) ** 2).sum() / max((b[ok] ** 2).sum(), 1e-30)))
+
+
+# ---- morph targets ----------------------------------------------------------------------------------------------------------------
+def _morph_scene():
+    s = scenes.skinned_figure(64, 36)
+    scenes.add_morph_targets(s)
+    return s
+
+
+def _run_skin(backend, s, use_mfma, morph, t=0.37, bones=True, in_flags=None):
+    h = s.upload(backend)
+    bind = scenes.SkinBinding(backend, s, h, 0, use_mfma, morph=morph)
+    if in_flags is not None:
+        bind.params.input_mesh_flags = in_flags
+    bind.pose(t, bones=bones)
+    nv = s.skins[0]["mesh"].num_vertices
+    return (backend.buffer_read(bind.out_position, np.float32, nv * 3).reshape(-1, 3), backend.buffer_read(bind.out_tangent_space, np.uint32, nv))
+
+
+def _packed_fields_close(tg, to, min_equal):
+    """10-10-10-2 tangent spaces: a field may sit one quantisation step off where a value lies on a rounding edge."""
+    d = [np.abs(((tg >> sh) & 0x3ff).astype(int) - ((to >> sh) & 0x3ff).astype(int)) for sh in (0, 10)]
+    assert max(x.max() for x in d) <= 1, [int(x.max()) for x in d]
+    ang = np.abs(((tg >> 20) & 0x3ff).astype(int) - ((to >> 20) & 0x3ff).astype(int)); ang = np.minimum(ang, 1023 - ang)
+    assert ang.max() <= 2, int(ang.max())
+    assert np.all((tg >> 30) == (to >> 30))
+    assert np.mean(tg == to) >= min_equal, float(np.mean(tg == to))
+
+
+def _f64_positions(s, morph, t, bones):
+    """Skin.cs.hlsl:61-103 for the positions in float64: p' = sum_i w_i B_i (p + sum_k m_k dP_k)."""
+    sk = s.skins[0]; mesh = sk["mesh"]
+    p = mesh.positions.astype(np.float64).copy()
+    for ti, w in morph:
+        src = sk["targets"][ti]["sources"]
+        if "POSITION" in src:
+            p += float(np.float32(w)) * src["POSITION"].astype(np.float64)
+    if not bones:
+        return p
+    B = scenes.bones_for_pose(sk, np.eye(4), scenes.skinned_figure_pose(t))
+    M = np.stack([np.array(b.transform[:], np.float64).reshape(4, 4).T for b in B])           # column-major storage
+    jw = scenes.meshgen.pack_joint_weight(mesh.joints, mesh.weights)
+    ids = jw[:, :4].astype(int); w = jw[:, 4:].astype(np.float64) / 65535.0
+    ph = np.concatenate([p, np.ones((len(p), 1))], axis=1)
+    out = np.zeros_like(p)
+    for k in range(4):
+        out += w[:, k:k + 1] * np.einsum("nij,nj->ni", M[ids[:, k]], ph)[:, :3]
+    return out
+
+
+MORPH_CASES = [
+    ("one position-only target", [(1, 0.8)]),
+    ("one target with tangent space", [(0, 0.6)]),
+    ("tangent-space-only target", [(3, 0.9)]),
+    ("position + normal (EncodeNormal) target", [(2, 0.5)]),
+    ("two targets", [(0, 0.3), (1, 0.7)]),
+    ("three targets", [(2, 0.25), (3, 0.5), (5, 1.0)]),
+    ("four targets", [(0, 0.4), (1, 0.15), (4, 0.9), (2, 0.6)]),
+]
+
+
+@pytest.mark.parametrize("use_mfma", [0, 1])
+@pytest.mark.parametrize("case", MORPH_CASES, ids=[c[0] for c in MORPH_CASES])
+def test_morphed_and_skinned_mesh_matches_oracle(R, oracle_lib, use_mfma, case):
+    """Skin.cs.hlsl:70-88 followed by :91-128: morph targets applied to position / normal / tangent, then the four-joint blend."""
+    _, morph = case
+    s = _morph_scene()
+    r = R(); o = oracle_lib.Oracle()
+    pg, tg = _run_skin(r, s, use_mfma, morph)
+    po_, to_ = _run_skin(o, s, 0, morph)
+    scale = max(1.0, float(np.abs(po_).max()))
+    e = float(np.abs(pg - po_).max())
+    assert e < 2e-6 * scale * (8 if use_mfma else 1), e
+    ref = _f64_positions(s, morph, 0.37, True)
+    assert np.abs(po_ - ref).max() < 2e-5 and np.abs(pg - ref).max() < 2e-5              # both sides against the float64 restatement
+    _packed_fields_close(tg, to_, 0.95 if use_mfma else 0.97)
+    # the targets matter: the unmorphed skin is measurably elsewhere (positions when a target moves them, tangent spaces otherwise)
+    p0, t0 = _run_skin(r, s, use_mfma, None)
+    if any("POSITION" in s.skins[0]["targets"][ti]["sources"] for ti, _ in morph):
+        assert np.abs(pg - p0).max() > 0.01
+    if any("NORMAL" in s.skins[0]["targets"][ti]["sources"] for ti, _ in morph):
+        assert np.mean(tg != t0) > 0.5
+    print("morph [%s] mfma=%d: max |dp| vs oracle %.2e, packed words equal %.4f" % (case[0], use_mfma, e, float(np.mean(tg == to_))))
+    r.close(); o.close()
+
+
+@pytest.mark.parametrize("case", [MORPH_CASES[1], MORPH_CASES[4], MORPH_CASES[6]], ids=lambda c: c[0])
+def test_morph_only_mesh_without_bones_loses_its_input_flags_like_the_reference(R, oracle_lib, case):
+    """quirk q19 (GpuSkin.cpp:94): with no bone buffer `input_mesh_flags &= !FLAG_JOINT_WEIGHT` clears EVERY input flag, so a
+    morphed, unskinned mesh starts from normal = 0, tangent = (0,0,0,1): its output tangent space is made of the morph deltas alone."""
+    _, morph = case
+    s = _morph_scene()
+    r = R(); o = oracle_lib.Oracle()
+    flags = abi.MESH_FLAG_INDEX | abi.MESH_FLAG_TANGENT_SPACE | abi.MESH_FLAG_TEXCOORD_0 | abi.MESH_FLAG_JOINT_WEIGHT
+    pg, tg = _run_skin(r, s, 1, morph, bones=False, in_flags=flags)
+    po_, to_ = _run_skin(o, s, 0, morph, bones=False, in_flags=flags)
+    assert np.array_equal(pg, po_)                                                        # p + sum w dP in the same order: the same bits
+    assert np.abs(pg - _f64_positions(s, morph, 0.37, False)).max() < 1e-6
+    # every field within one step; identical words in ~97 %: the tangent of a morph-only vertex is a DECODED 10-bit angle, and re-encoding it
+    # (angle / 2 pi + 0.5, quirk q25's half turn) lands exactly on a truncation edge of the 10-bit field, so the last bit of atan2f decides
+    _packed_fields_close(tg, to_, 0.95)
+    # ... and NOT what a correct `&= ~FLAG_JOINT_WEIGHT` would give (rest normals + deltas): the quirk is observable
+    sk = s.skins[0]
+    rest_ts = sk["mesh"].tangent_space_stream()
+    assert np.mean((tg & 0xfffff) != (rest_ts & 0xfffff)) > 0.9
+    r.close(); o.close()
+
+
+def test_morph_only_position_targets_without_bones_nan_tangent_space_is_identical(R, oracle_lib):
+    """q19 with position-only targets: normal and tangent stay (0,0,0), normalize() makes NaN, and the 10-10-10-2 encode of NaN
+    must come out the same on both sides (float -> uint of NaN is 0 in HLSL)."""
+    s = _morph_scene()
+    r = R(); o = oracle_lib.Oracle()
+    pg, tg = _run_skin(r, s, 0, [(1, 0.5), (5, 0.25)], bones=False)
+    po_, to_ = _run_skin(o, s, 0, [(1, 0.5), (5, 0.25)], bones=False)
+    assert np.array_equal(pg, po_)
+    assert np.array_equal(tg, to_), (np.unique(tg)[:4], np.unique(to_)[:4])
+    r.close(); o.close()
+
+
+def test_gltf_morph_weights_pick_the_four_largest_targets(R, tmp_path):
+    """glTF file with six morph targets and six node weights -> loader -> gs_frame (PerformSkinning: the four largest positive
+    weights, Renderer.cpp:425-443) -> pt_skin_run, against the procedural scene bound to the targets the Python restatement picks."""
+    from tests.scene_export import skinned_figure_to_builder
+    from tests.test_gpu_gltf import render_direct, render_loaded
+    weights = [0.30, 0.10, 0.0, 0.45, 0.20, 0.25]                    # target 2 is not positive; 5 then replaces 1 (the smallest held)
+    picked = scenes.pick_morph_targets(weights)
+    assert [t for t, _ in picked] == [0, 5, 3, 4]
+    s = scenes.skinned_figure(160, 90)
+    scenes.add_morph_targets(s)
+    path = skinned_figure_to_builder(s, morph_weights=weights).write_glb(str(tmp_path / "morph_figure.glb"))
+    t = 0.8
+    a, _ = render_direct(R, s, 16, lambda r, h: scenes.SkinBinding(r, s, h, 0, 1, morph=picked).pose(t))
+    b, _ = render_loaded(R, s, path, 16, animate_time=t)
+    plain, _ = render_direct(R, s, 16, lambda r, h: scenes.SkinBinding(r, s, h, 0, 1).pose(t))
+    wrong, _ = render_direct(R, s, 16, lambda r, h: scenes.SkinBinding(r, s, h, 0, 1, morph=[(0, 0.30), (1, 0.10), (3, 0.45), (4, 0.20)]).pose(t))
+    e = rel_l2(b, a)
+    print("morphed glTF against the procedural binding: rel L2 %.3e (unmorphed: %.3e, first-four pick: %.3e)" % (e, rel_l2(plain, a), rel_l2(wrong, a)))
+    assert e <= 1e-4, e
+    assert rel_l2(plain, a) > 20 * e and rel_l2(wrong, a) > 20 * e
+
+
+# ---- one exact-BASELINE-size single-sample frame per config against the oracle ---------------------------------------------------
+def _fullsize_frame(R, oracle_lib, s, name, prepare=None, frame=0, expect_rays_per_pixel=(1.0, 60.0)):
+    import time
+    import oracle.pyoracle as po
+    r = R(); hg = s.upload(r)
+    env_raw = r.env_read(hg["env"]) if hg["env"] is not None else None
+    o = oracle_lib.Oracle(); ho = s.upload(o, env_raw=env_raw)
+    if prepare:
+        prepare(r, hg); prepare(o, ho)
+    st = copy_settings(s.settings); st.flags &= ~abi.FLAG_ACCUMULATE
+    og = r.create_output(s.width, s.height)
+    b = np.zeros((s.height, s.width, 4), np.float32)
+    r.reset_stats(); o.counters()
+    r.trace(st, s.execute_params(frame, env_handle=hg["env"]), og)
+    t0 = time.time()
+    o.trace(st, s.execute_params(frame, env_handle=ho["env"]), b)
+    t_oracle = time.time() - t0
+    a = r.readback(og)
+    sg, so = r.stats(), o.counters()
+    n = s.width * s.height
+    A = a[..., :3].astype(np.float64); B = b[..., :3].astype(np.float64)
+    assert np.isfinite(A).all() and np.isfinite(B).all()
+    rel = np.abs(A - B).max(axis=2) / np.maximum(np.abs(B).max(axis=2), 1e-4)
+    beyond3, beyond2 = int((rel > 1e-3).sum()), int((rel > 1e-2).sum())
+    e = rel_l2(r.tonemap(og), po.tonemap(b))
+    print("%s %dx%d 1 spp: rays GPU %d / oracle %d (p %d b %d s %d), pixel-samples beyond 1e-3: %d, beyond 1e-2: %d of %d, median rel %.1e, "
+          "tone-mapped rel L2 %.3e; GPU %.2f ms, oracle %.1f s" % (name, s.width, s.height, sg.rays, so["rays"], so["primary"], so["bounce"], so["shadow"],
+                                                                   beyond3, beyond2, n, float(np.median(rel)), e, sg.trace_ms, t_oracle))
+    assert (sg.rays_primary, sg.rays_bounce, sg.rays_shadow, sg.closest_hits) == (so["primary"], so["bounce"], so["shadow"], so["closest_hits"])
+    assert expect_rays_per_pixel[0] * n <= sg.rays <= expect_rays_per_pixel[1] * n
+    assert beyond3 <= 1e-4 * n, (beyond3, n)          # a pixel-sample that parts from the oracle is a different PATH (a flipped discrete decision), counted
+    assert e <= 1e-3, e                               # the north_star contract
+    r.close(); o.close()
+    return sg, so, e
+
+
+def test_config2_helmet_class_exact_size_frame_matches_the_oracle(R, oracle_lib):
+    """BASELINE config 2: 1920x1080, 4 bounces, 81,920 triangles, five 2048^2 textures, 2048x1024 sky, environment MIS."""
+    s = scenes.helmet_class()
+    assert (s.width, s.height, s.settings.max_bounces) == (1920, 1080, 4) and s.textures[0][0].shape[:2] == (2048, 2048)
+    _fullsize_frame(R, oracle_lib, s, "config 2 (helmet class)")
+
+
+def test_config3_sponza_class_exact_size_frame_matches_the_oracle(R, oracle_lib):
+    """BASELINE config 3, the bench workload itself: 1920x1080, 8 bounces + RR, ~262 k triangles, forty 1024^2 textures (with their
+    208 MB of interleaved footprint copies: the one case that lives beyond the Infinity Cache), punctual lights + environment MIS."""
+    s = scenes.sponza_class()
+    assert (s.width, s.height, s.settings.max_bounces) == (1920, 1080, 8)
+    assert len(s.textures) >= 40 and s.textures[0][0].shape[:2] == (1024, 1024) and s.triangles > 250000
+    _fullsize_frame(R, oracle_lib, s, "config 3 (Sponza class)")
+
+
+def test_config4_material_grid_exact_size_frame_matches_the_oracle(R, oracle_lib):
+    """BASELINE config 4: 1024x1024, 16 bounces, the KHR_materials_* grid (transmission, clearcoat, sheen, anisotropy)."""
+    s = scenes.material_grid()
+    assert (s.width, s.height, s.settings.max_bounces) == (1024, 1024, 16)
+    _fullsize_frame(R, oracle_lib, s, "config 4 (material grid)")
+
+
+def test_config5_skinned_figure_4k_exact_size_frame_matches_the_oracle(R, oracle_lib):
+    """BASELINE config 5: 3840x2160, 8 bounces, the figure skinned to a walk-cycle pose on both sides (skin -> build -> trace)."""
+    s = scenes.skinned_figure()
+    assert (s.width, s.height, s.settings.max_bounces) == (3840, 2160, 8)
+    _fullsize_frame(R, oracle_lib, s, "config 5 (skinned figure, 4K)", prepare=lambda backend, h: scenes.SkinBinding(backend, s, h, 0, 0).pose(0.55))
+
+
+# ---- the N > 1 branches of pt_exchange_frame, run for real through the in-process loopback transport -------------------------------
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("mode", [abi.EXCHANGE_GATHER, abi.EXCHANGE_REDUCE], ids=["gather", "reduce"])
+def test_exchange_frame_of_n_ranks_equals_the_one_rank_frame(R, world, mode):
+    """N contexts on one GPU, each rendering its tile shard (tile % N == rank) into its OWN accumulation image, assembled by the real
+    exchange_frame (exchange.hip) over the loopback transport: the root's per-rank receive offsets, the other ranks' sends, per-rank
+    unpack, the reduce of the zero-masked copies.  Three accumulated frames with an exchange after each, a ragged image (edge tiles
+    partly outside, tile count not a multiple of N, at N = 8 more ranks than some tile columns), root = the last rank once.
+    Bit-equal to the 1-rank running mean.  (RCCL itself needs one GPU per rank: the driver's multi-GPU run is its first execution.)"""
+    import torch
+    s = scenes.test_scene(96, 32)
+    s.width, s.height = 150, 70                        # 10 x 5 tiles, the last column and row ragged
+    st = copy_settings(s.settings)
+    ref = R(); hr = s.upload(ref)
+    want = ref.create_output(s.width, s.height)
+    ranks = []
+    group = 1000 + world * 10 + mode
+    for k in range(world):
+        r = R(); h = s.upload(r)
+        r.exchange_create_loopback(k, world, group)
+        ranks.append((r, h, r.create_output(s.width, s.height)))
+    for dst in (0, world - 1):
+        frames = [r.create_output(s.width, s.height) for r, _, _ in ranks]
+        for f in range(3):
+            stf = copy_settings(st); stf.reset = 1 if f == 0 else 0
+            ref.trace(stf, s.execute_params(f, env_handle=hr["env"]), want)
+            order = [k for k in range(world) if k != dst] + [dst]           # posted transfers: the root is called last
+            for k in order:
+                r, h, acc = ranks[k]
+                r.trace(stf, s.execute_params(f, env_handle=h["env"], tile_rank=k, tile_rank_count=world), acc)
+                r.exchange_frame(acc, frames[k] if f < 2 else None, mode=mode, dst=dst)          # last frame: assembled in place on the root
+            torch.cuda.synchronize()
+            got = frames[dst] if f < 2 else ranks[dst][2]
+            assert torch.equal(got, want), (world, mode, dst, f, float((got - want).abs().max()))
+        # after the in-place assembly the root's own image holds the other ranks' tiles too: its next reset frame starts clean (reset = 1 above)
+    # calling the root first is refused, not deadlocked
+    from gltf_renderer_amd.renderer import MiptError
+    r0, h0, acc0 = ranks[0]
+    with pytest.raises(MiptError, match="after the other ranks|has not"):
+        r0.exchange_frame(acc0, None, mode=mode, dst=0)
+    with pytest.raises(MiptError, match="dst_rank"):
+        r0.exchange_frame(acc0, None, mode=mode, dst=world)
+    for r, _, _ in ranks:
+        r.exchange_destroy(); r.close()
+    ref.close()
+
+
+def test_bench_launches_its_own_ranks_when_started_plainly(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it must start two rank processes itself (torch.distributed.run as a child) and
+    report n_gpus = 2.  One GPU here, so the ranks share it and exchange through the gloo test double (`--backend gloo --single-device`,
+    labelled a rehearsal in the line): what is under test is the launch path and the rank bookkeeping, not RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device", "--config", "test",
+                          "--steps", "2", "--warmup", "1", "--no-weak"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["value"] > 0
+    assert "REHEARSAL" in res["config"]["parallelism"]
+
+
+# ---- trees deeper than the 64-entry on-chip stack are rendered, not refused ----------------------------------------------------------
+def _deep_chain_scene(dups=4096, size=32):
+    """A legal scene whose radix tree needs more traversal-stack entries than a lane holds on chip, and whose rays really use them.
+    57 thin sheets perpendicular to the view direction (+x) whose bounding-box centres are (C,0,0), (0,C,0) or (0,0,C) with
+    C = (2^j + 1/4) 2^-10, j = 0..18 -- long thin triangles for the y and z kinds: every Morton code has a different highest bit, so the
+    radix tree is one chain, 57 binary levels deep -- plus `dups` coincident copies of the nearest sheet (equal codes: a subtree balanced by
+    index below the chain's end).  Each chain level's sheet lies farther along the ray than everything below it, so a ray enters the inner
+    child first and leaves the sheets on its stack: ~3 entries per wide level all the way down, then 3 more per level of the copies."""
+    from gltf_renderer_amd import camera, meshgen
+    f32 = np.float32
+    u, h, w, eps = 2.0 ** -10, 2.0 ** -10, 2.0 ** -11, 2.0 ** -20
+    tris = [[(-eps, -h, -h), (-eps, h, -h), (-eps, 0, h)]] * dups                 # the nearest sheet, `dups` times
+    k = 0
+    for j in range(19):
+        C = (2.0 ** j + 0.25) * u
+        xk = (k + 1) * eps; k += 1
+        tris.append([(xk, -h, -w), (xk, -h, 2 * C + w), (xk, h, -w)])             # centre (~0, 0, C): long along z
+        xk = (k + 1) * eps; k += 1
+        tris.append([(xk, -w, -h), (xk, 2 * C + w, -h), (xk, -w, h)])             # centre (~0, C, 0): long along y
+        k += 1
+        tris.append([(C, -h, -h), (C, h, -h), (C, 0, h)])                         # centre (C, 0, 0)
+    pos = np.array(tris, f32)[:, [0, 2, 1], :].reshape(-1, 3)                     # wound so that the geometric normal faces the camera (-x)
+    n = len(pos) // 3
+    mesh = meshgen.Mesh(pos, np.arange(3 * n), normals=np.tile(np.array([[-1, 0, 0]], f32), (3 * n, 1)),
+                        uv0=np.tile(np.array([[0, 1], [1, 1], [0.5, 0]], f32), (n, 1)))
+    s = scenes.single_triangle(size)
+    s.instances.clear(); s.mesh_records.clear(); s.buffers.clear(); s.triangles = 0
+    m = s.add_material(scenes.material(base_color_factor=(0.8, 0.6, 0.4, 1.0), flags=abi.MATERIAL_FLAG_DOUBLE_SIDED))
+    s.add_mesh(mesh, None, m)
+    s.world_to_view = camera.free_world_to_view((-0.5, 0.0, 0.0), yaw=-np.pi / 2)
+    assert np.allclose(s.world_to_view @ np.array([1.0, 0, 0, 0]), [0, 0, -1, 0], atol=1e-12)          # looking along +x
+    s.ortho = (1.0 / (0.15 * h), 1.0 / (0.15 * h))                                # half extents 1 / mag: every ray inside every sheet
+    st = abi.PtSettings.app_defaults(); st.min_bounces, st.max_bounces = 1, 2
+    st.flags &= ~(abi.FLAG_ENVIRONMENT_MAP | abi.FLAG_ENVIRONMENT_MIS)            # no map: the constant colour lights the scene
+    st.environment_color[:] = (1.0, 1.0, 1.0)
+    s.settings = st
+    return s, n
+
+
+@pytest.mark.parametrize("mode", [abi.MODE_WAVEFRONT, abi.MODE_MEGAKERNEL], ids=["wavefront", "megakernel"])
+def test_tree_deeper_than_the_on_chip_stack_is_rendered_not_refused(R, oracle_lib, mode):
+    """a tree that needs more than 64 stack entries made pt_build_accel fail with PT_ERR_CAPACITY -- a legal glTF refused outright,
+    where the reference's driver BVH at worst skips one primitive (RayTracingAccelerationStructure.cpp:137-140).  Now the rays of such a
+    tree get a deep stack in memory for the entries beyond 64: same hits as the clustering builder's (shallower) tree and as the oracle's
+    brute-force loop, no push dropped, and the deep entries are really written."""
+    s, n = _deep_chain_scene()
+    imgs, rad = {}, {}
+    for b in (abi.BUILDER_LBVH, abi.BUILDER_PLOC_REINSERT):
+        r = R(); r.set_kernel_mode(mode); r.set_accel_builder(b); h = s.upload(r)
+        r.reset_stats()
+        st = copy_settings(s.settings); st.debug_output = abi.DEBUG_OUTPUT_TEXCOORD_0; st.flags &= ~abi.FLAG_ACCUMULATE; st.use_frame_as_seed = 0; st.seed = 3
+        out = r.create_output(s.width, s.height)
+        r.trace(st, s.execute_params(0), out)
+        imgs[b] = r.readback(out)
+        st2 = copy_settings(s.settings); st2.reset = 1
+        out2 = r.create_output(s.width, s.height)
+        for f in range(2):
+            r.trace(st2, s.execute_params(40 + f), out2); st2.reset = 0
+        rad[b] = r.readback(out2)
+        q = r.stats()                                    # raises if a push was dropped (PT_ERR_CAPACITY "traversal stack overflow")
+        print("deep chain, builder %d, mode %d: %d triangles, stack need %d, capacity %d, deep pushes %d, builder fallbacks %d"
+              % (b, mode, q.bvh_triangles, q.bvh_stack_need, q.bvh_stack_capacity, q.deep_stack_pushes, q.accel_builder_fallbacks))
+        assert q.bvh_triangles == n and q.bvh_stack_capacity >= q.bvh_stack_need
+        if b == abi.BUILDER_LBVH:
+            assert q.bvh_stack_need > 64, q.bvh_stack_need        # the scene is what it claims to be
+            assert q.deep_stack_pushes > 0                        # and its rays went there
+        r.close()
+    assert np.array_equal(imgs[abi.BUILDER_LBVH], imgs[abi.BUILDER_PLOC_REINSERT])
+    assert np.array_equal(rad[abi.BUILDER_LBVH], rad[abi.BUILDER_PLOC_REINSERT]) and rad[abi.BUILDER_LBVH][..., :3].mean() > 0.05
+    # ground truth: the oracle's brute-force loop over all triangles (no tree at all)
+    o = oracle_lib.Oracle(); o.set_brute_force(True); ho = s.upload(o)
+    st = copy_settings(s.settings); st.debug_output = abi.DEBUG_OUTPUT_TEXCOORD_0; st.flags &= ~abi.FLAG_ACCUMULATE; st.use_frame_as_seed = 0; st.seed = 3
+    b = np.zeros((s.height, s.width, 4), np.float32)
+    o.trace(st, s.execute_params(0), b)
+    assert np.abs(imgs[abi.BUILDER_LBVH][..., :3] - b[..., :3]).max() < 1e-5
+    assert (b[..., :2].max(axis=2) > 0).all()                    # every ray hits the nearest sheet
+    o.close()
+
+
+@pytest.mark.parametrize("axis", ["-z (top down)", "+y", "+x"])
+def test_axis_aligned_orthographic_camera_matches_the_oracle(R, oracle_lib, axis):
+    """Rays with direction components that are EXACTLY zero (an orthographic camera looking along a world axis).  The traversal's slab
+    test is plane * (1 / d) - origin * (1 / d): with 1 / 0 = inf both products are infinite and their difference NaN, and such a ray
+    missed every box it was inside of -- the whole scene rendered as sky (found by the deep-tree test above, fixed by clamping 1 / d in
+    trav_init).  Primary hits and radiance against the oracle, whose slab test is (plane - origin) / d."""
+    import oracle.pyoracle as po
+    from gltf_renderer_amd import camera
+    s = scenes.test_scene(96, 64)
+    s.ortho = (0.3, 0.45)
+    if axis.startswith("-z"):
+        # FreeController looks along +y at pitch 0; pitch -90 degrees looks straight down
+        s.world_to_view = camera.free_world_to_view((0.1, 0.2, 6.0), yaw=0.0, pitch=-np.pi / 2)
+        fwd = [0, 0, -1]
+    elif axis == "+y":
+        s.world_to_view = camera.free_world_to_view((0.1, -6.0, 1.2), yaw=0.0, pitch=0.0)
+        fwd = [0, 1, 0]
+    else:
+        s.world_to_view = camera.free_world_to_view((-6.0, 0.2, 1.2), yaw=-np.pi / 2, pitch=0.0)
+        fwd = [1, 0, 0]
+    got = s.world_to_view @ np.array(fwd + [0], np.float64)
+    assert np.allclose(got, [0, 0, -1, 0], atol=1e-9), got                           # view space looks down -z
+    # make the zero components exact: the rotation's cos(pi / 2) is 6e-17, not 0
+    s.world_to_view = np.where(np.abs(s.world_to_view) < 1e-12, 0.0, s.world_to_view)
+    r = R(); hg = s.upload(r)
+    o = oracle_lib.Oracle(); ho = s.upload(o, env_raw=r.env_read(hg["env"]))
+    st = copy_settings(s.settings); st.debug_output = abi.DEBUG_OUTPUT_HIT_KIND; st.flags &= ~abi.FLAG_ACCUMULATE; st.use_frame_as_seed = 0; st.seed = 1
+    og = r.create_output(s.width, s.height); b = np.zeros((s.height, s.width, 4), np.float32)
+    r.trace(st, s.execute_params(0, env_handle=hg["env"]), og); o.trace(st, s.execute_params(0, env_handle=ho["env"]), b)
+    a = r.readback(og)
+    hit = ((b[..., 0] == 1) & (b[..., 1] == 0)) | ((b[..., 0] == 0) & (b[..., 1] == 1))
+    assert hit.mean() > 0.05, float(hit.mean())                                     # the scene is in view
+    assert (np.abs(a - b).max(axis=2) > 1e-4).mean() < 0.002, float((np.abs(a - b).max(axis=2) > 1e-4).mean())
+    st = copy_settings(s.settings); st.reset = 1
+    og = r.create_output(s.width, s.height); b = np.zeros((s.height, s.width, 4), np.float32)
+    for f in range(32):
+        r.trace(st, s.execute_params(f, env_handle=hg["env"]), og); o.trace(st, s.execute_params(f, env_handle=ho["env"]), b); st.reset = 0
+    e = rel_l2(r.tonemap(og), po.tonemap(b))
+    print("axis-aligned orthographic camera %s: primary hits on %.0f %% of the pixels, tone-mapped rel L2 %.3e at 32 spp" % (axis, 100 * hit.mean(), e))
+    assert e <= 1e-3, e
+    r.close(); o.close()

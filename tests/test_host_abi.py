@@ -227,3 +227,24 @@ int main() {
     exe = tmp_path / "fastdiv"
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", str(tmp_path), "-o", str(exe), str(src)])
     assert subprocess.run([str(exe)], capture_output=True, text=True).stdout.strip() == "0"
+
+
+def test_rccl_that_cannot_be_loaded_is_reported_not_crashed():
+    """rccl() built its message from two dlerror() calls (the second returns NULL: undefined behaviour) -- a host without a
+    loadable librccl must get PT_ERR_NOT_READY from pt_exchange_probe / pt_exchange_unique_id, as include/mipt.h documents.
+    MIPT_RCCL_LIBRARY points the loader at a file that does not exist; a fresh process, because the binding is made once."""
+    import subprocess
+    import sys
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r)\n"
+            "from gltf_renderer_amd import renderer\n"
+            "L = renderer.load_library()\n"
+            "buf = (C.c_ubyte * 128)()\n"
+            "print(L.pt_exchange_probe(), L.pt_exchange_unique_id(buf), L.pt_exchange_probe())\n" % ROOT)
+    env = dict(os.environ, MIPT_RCCL_LIBRARY="/nonexistent/librccl.so.1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split() == ["-6", "-6", "-6"], out.stdout           # PT_ERR_NOT_READY, three times, no crash
+    # and with the default search list the library is found here (ROCm image): the probe does not touch a GPU
+    out = subprocess.run([sys.executable, "-c", code], env={k: v for k, v in os.environ.items() if k != "MIPT_RCCL_LIBRARY"}, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[0] == "0", out.stdout

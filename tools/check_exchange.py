@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Rehearsal on a 1-GPU box: N ranks (gloo, all on cuda:0) render their tile shards of one frame and assemble it on rank 0
-with both exchange forms of the torch.distributed test double (gltf_renderer_amd/sharding.py) -- and moves the tiles through
+with both exchange forms of the torch.distributed test double (tests/sharding_double.py) -- and moves the tiles through
 libmipt.so's own pack / unpack kernels (pt_tiles_pack / pt_tiles_unpack, the device half of pt_exchange_frame) --; rank 0 also renders the whole frame alone.  All three must be
 bit-identical.  Launch:  python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/check_exchange.py"""
 import os
@@ -20,7 +20,7 @@ def main():
     dist.init_process_group("gloo")
     from gltf_renderer_amd import abi, scenes
     from gltf_renderer_amd.renderer import Renderer
-    from gltf_renderer_amd.sharding import TileExchange
+    from tests.sharding_double import TileExchange
     s = scenes.test_scene(200, 64)
     s.width, s.height = 200, 136                       # partial edge tiles in both directions
     r = Renderer(0)

@@ -1,8 +1,6 @@
 #!/bin/bash
-# Run ON THE GPU BOX: tools/builder_probe.py <scene> with every variants/libmipt_*.so swapped in.
-cp gltf_renderer_amd/libmipt.so /tmp/orig_pv.so
+# Run ON THE GPU BOX: tools/builder_probe.py <scene> with every variants/libmipt_*.so, selected through MIPT_LIBRARY (the tree's product
+# library is never overwritten).
 for f in variants/libmipt_*.so; do
-  cp "$f" gltf_renderer_amd/libmipt.so
-  echo "== $f"; timeout -k 5 200 python tools/builder_probe.py ${1:-sponza} 2>&1 | grep "reins \|differ"
+  echo "== $f"; MIPT_LIBRARY=$PWD/$f timeout -k 5 200 python tools/builder_probe.py ${1:-sponza} 2>&1 | grep "reins \|differ"
 done
-cp /tmp/orig_pv.so gltf_renderer_amd/libmipt.so

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cmath>
 #include "../../gltf_renderer_amd/csrc/pt_math.h"      // pt::fdiv, pt::hpow: the library's own functions are what is checked
 __device__ __forceinline__ uint32_t pcg(uint32_t& s) { s = s * 747796405u + 2891336453u; uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u; return (w >> 22u) ^ w; }
 __device__ __forceinline__ float rnd_float(uint32_t& s, int emin, int emax) {          // random sign, exponent in [emin, emax], random mantissa
@@ -48,7 +49,24 @@ __global__ void k(unsigned long long* bad, int rounds, int emin, int emax) {
     }
     atomicAdd(&bad[0], b1); atomicAdd(&bad[1], b2); atomicAdd(&bad[2], s1); atomicAdd(&bad[3], s2);
 }
+// The operands OUTSIDE fdiv's contract: what it returns where the IEEE quotient is +-inf or a large finite number.
+__global__ void k_special(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ lean, float* __restrict__ ieee, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { lean[i] = pt::fdiv(a[i], b[i]); ieee[i] = a[i] / b[i]; }
+}
+static void special_cases() {
+    const float A[] = {3.0e38f, 1.0e30f, -2.0e20f, 1.0f, 5.0f, 1.0e-30f, 1.0f, 0.0f, 1.0f, INFINITY};
+    const float B[] = {1.0e-3f, 1.0e-20f, 1.0e-25f, 1.0e-40f, -3.0e-42f, 1.0e-39f, 0.0f, 0.0f, INFINITY, 2.0f};
+    const int n = (int)(sizeof(A) / sizeof(A[0]));
+    float *da, *db, *dl, *di, L[16], I[16];
+    hipMalloc(&da, n * 4); hipMalloc(&db, n * 4); hipMalloc(&dl, n * 4); hipMalloc(&di, n * 4);
+    hipMemcpy(da, A, n * 4, hipMemcpyHostToDevice); hipMemcpy(db, B, n * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_special, dim3(1), dim3(64), 0, 0, da, db, dl, di, n);
+    hipMemcpy(L, dl, n * 4, hipMemcpyDeviceToHost); hipMemcpy(I, di, n * 4, hipMemcpyDeviceToHost);
+    for (int i = 0; i < n; i++) printf("special %d: %g / %g -> fdiv %g , ieee %g\n", i, (double)A[i], (double)B[i], (double)L[i], (double)I[i]);
+}
 int main() {
+    special_cases();
     unsigned long long* d; hipMalloc(&d, 32);
     const int ranges[][2] = {{-10, 10}, {-40, 40}, {-60, 60}, {-1, 0}};
     for (auto& r : ranges) {

@@ -125,9 +125,33 @@ if stages:
     stages["pipeline"] = {"kernel_ms_per_launch": ms, "hbm_bytes_per_launch_raw": (fe + wr) * 1024.0, "hbm_bytes_per_launch": (2 * fe + wr) * 1024.0,
                           "hbm_GBps": (2 * fe + wr) * 1024.0 / max(ms, 1e-9) / 1e6, "l2_hit_rate": hit / max(hit + miss, 1.0)}
     spp = (summary.get("bench") or {}).get("config", {}).get("samples_per_step")
+    # the same per individual kernel (bench.py's roofline names the single dominant kernel, k_wf_traverse, beside its family)
+    per_kernel = defaultdict(lambda: defaultdict(float))
+    kname = lambda nm: next((k for k in ("k_wf_traverse", "k_wf_trace", "k_wf_shadow", "k_wf_shade", "k_wf_generate", "k_wf_resolve", "pt_megakernel") if k in nm), None)
+    for sub in ("pmc_fetch", "pmc_write", "pmc_l2"):
+        for f in find(sub + "/**/*counter_collection.csv"):
+            for row in csv.DictReader(open(f)):
+                k = kname(row.get("Kernel_Name", ""))
+                if k:
+                    per_kernel[k][row["Counter_Name"]] += float(row["Counter_Value"]) / max(pmc_frames, 1)
+    kern = {}
+    for name, v in per.items():
+        k = kname(name)
+        if k:
+            kern.setdefault(k, {"kernel_ms_per_launch": 0.0, "launches_per_pt_trace": 0.0})
+            kern[k]["kernel_ms_per_launch"] += sum(d[0] for d in v) / 1e6 / max(trace_frames, 1)
+            kern[k]["launches_per_pt_trace"] += len(v) / max(trace_frames, 1)
+    lines.append("per-kernel PMC, per launch (= per pt_trace): kernel | launches | ms | HBM bytes (FETCH x2 + WRITE) | TCC hit rate")
+    for k, cs in sorted(per_kernel.items()):
+        fe, wr, hit, miss = cs.get("FETCH_SIZE", 0.0), cs.get("WRITE_SIZE", 0.0), cs.get("TCC_HIT_sum", 0.0), cs.get("TCC_MISS_sum", 0.0)
+        e = kern.setdefault(k, {"kernel_ms_per_launch": 0.0, "launches_per_pt_trace": 0.0})
+        e.update({"FETCH_SIZE_KB": fe, "WRITE_SIZE_KB": wr, "TCC_HIT_sum": hit, "TCC_MISS_sum": miss, "hbm_bytes_per_launch_raw": (fe + wr) * 1024.0,
+                  "hbm_bytes_per_launch": (2.0 * fe + wr) * 1024.0, "l2_hit_rate": hit / max(hit + miss, 1.0)})
+        lines.append("%-16s %6.1f %9.3f %14.5g %8.4f" % (k, e["launches_per_pt_trace"], e["kernel_ms_per_launch"], e["hbm_bytes_per_launch"], e["l2_hit_rate"]))
+    head = os.environ.get("MIPT_GIT_HEAD") or (open(".build_head").read().strip() if os.path.exists(".build_head") else None)
     pk = {"source": "tools/profile_gpu.sh %s: rocprofv3 --kernel-trace pass + separate --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_HIT_sum TCC_MISS_sum passes of the same bench.py command; values per launch (= per pt_trace), summed over the launches of each kernel family" % tag,
           "correction": "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: gfx950 reports 1/2 of wide coalesced reads (MI355X_MICROARCH.md); our scattered 16-B gathers are an uncalibrated pattern, so the raw figure is kept beside it",
-          "samples_per_launch": spp, "stages": stages}
+          "samples_per_launch": spp, "git_head": head, "stages": stages, "kernels": kern}
     summary["pmc_per_kernel"] = pk
 
 fp = os.path.join(out_dir, "bench_trace.log")
