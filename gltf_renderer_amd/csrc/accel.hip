@@ -208,9 +208,9 @@ __global__ __launch_bounds__(256) void k_shade_packets(const TriPacket* __restri
         const float* q = in.p_position + (size_t)v * 3;
         o.pos[0] = q[0]; o.pos[1] = q[1]; o.pos[2] = q[2];
         if (in.p_tangent_space) o.tangent_space = in.p_tangent_space[v];
-        if (in.p_texcoord[0]) { float2 t = in.p_texcoord[0][v]; o.uv0[0] = t.x; o.uv0[1] = t.y; }
-        if (in.p_texcoord[1]) { float2 t = in.p_texcoord[1][v]; o.uv1[0] = t.x; o.uv1[1] = t.y; }
-        if (in.p_color) { uint2 c = in.p_color[v]; o.color[0] = c.x; o.color[1] = c.y; }
+        if (in.p_texcoord[0]) { float2 t = in.p_texcoord[0][v]; p.uv0[k][0] = t.x; p.uv0[k][1] = t.y; }
+        if (in.p_texcoord[1]) { float2 t = in.p_texcoord[1][v]; p.uv1[k][0] = t.x; p.uv1[k][1] = t.y; }
+        if (in.p_color) { uint2 c = in.p_color[v]; p.color[k][0] = c.x; p.color[k][1] = c.y; }
     }
     p.inst = tris[i].inst;
     const float4* s = (const float4*)&p;
@@ -1157,9 +1157,9 @@ __global__ __launch_bounds__(256) void k_refit_packets(const InstanceRec* __rest
         const float* q = in.p_position + (size_t)v * 3;
         o.pos[0] = q[0]; o.pos[1] = q[1]; o.pos[2] = q[2];
         if (in.p_tangent_space) o.tangent_space = in.p_tangent_space[v];
-        if (in.p_texcoord[0]) { float2 t = in.p_texcoord[0][v]; o.uv0[0] = t.x; o.uv0[1] = t.y; }
-        if (in.p_texcoord[1]) { float2 t = in.p_texcoord[1][v]; o.uv1[0] = t.x; o.uv1[1] = t.y; }
-        if (in.p_color) { uint2 c = in.p_color[v]; o.color[0] = c.x; o.color[1] = c.y; }
+        if (in.p_texcoord[0]) { float2 t = in.p_texcoord[0][v]; p.uv0[k][0] = t.x; p.uv0[k][1] = t.y; }
+        if (in.p_texcoord[1]) { float2 t = in.p_texcoord[1][v]; p.uv1[k][0] = t.x; p.uv1[k][1] = t.y; }
+        if (in.p_color) { uint2 c = in.p_color[v]; p.color[k][0] = c.x; p.color[k][1] = c.y; }
         w[k] = mul_point(in.gpu.transform, v3(q[0], q[1], q[2]));      // the expression k_setup evaluates: same bits as a rebuild
     }
     p.inst = inst;

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kBlock) void pt_megakernel(SceneRec sc, FrameConsta
         else if (!got) { L += shade_miss(sc, fc, ray.d, ps); alive = false; }
         else {
             n_hits++;
-            bool done = shade_closest_hit(sc, fc, fc.seed, px, py, ray, hit, load_shade_packet_raw(sc.shade + hit.tri), ps, fu, st.taps);
+            bool done = shade_closest_hit(sc, fc, fc.seed, px, py, ray, hit, load_shade_packet_raw(sc.shade + hit.tri), sc.shade + hit.tri, ps, fu, st.taps);
             if (fu.overwrite) L = v3(0);
             L += fu.add;
             n_shadow += fu.counted_shadow;

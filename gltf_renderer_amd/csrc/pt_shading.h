@@ -185,6 +185,9 @@ PT_DEV TexTaps texture_taps(const RTex& t, const vec2 tc[2]) {
     k.edge = k.i1 != k.ia && k.i1 != k.ia + 1;
     k.p0 = t.texels + (size_t)j0 * t.width;
     k.p1 = t.texels + (size_t)j1 * t.width;
+#ifdef PT_PROBE_NO_TEXELS     // PROBE ONLY (tools/pmc_shade_attribution.sh): every footprint is the texture's first texels -- wrong colours, what the texel gathers cost
+    k.i0 = 0; k.i1 = min(1, t.width - 1); k.ia = 0; k.edge = false; k.p0 = t.texels; k.p1 = t.texels;
+#endif
     return k;
 }
 PT_DEV uint2 tap_row(const TexTaps& k, int row) { return gload_u2((row ? k.p1 : k.p0) + k.ia); }
@@ -256,31 +259,38 @@ PT_DEV vec4 sample_slot(const SceneRec& sc, const RMat* m, int slot, const vec2 
 // ---------------------------------------------------------------- vertex fetch (PathTracer.lib.hlsl:176-302)
 // The three vertices of a hit triangle from its 128-B shading packet (pt_types.h ShadePacket: one cache line, 8 x dwordx4).
 struct PacketVerts { vec3 p[3]; uint32_t ts[3]; float2 uv0[3], uv1[3]; uint2 col[3]; uint32_t inst; };
-struct RawPacket { float4 r[8]; };                          // the eight loads, so that a caller can issue them ahead of their use
+struct RawPacket { float4 r[8]; };                          // the loads, so that a caller can issue them ahead of their use
+// the 80 B every hit needs (pt_types.h ShadePacket): five loads; the rest of the packet reads as zeros until load_shade_packet_extra
 PT_DEV RawPacket load_shade_packet_raw(const ShadePacket* pk) {
     const float4* q = (const float4*)pk;
     RawPacket p;
 #pragma unroll
-    for (int k = 0; k < 8; k++) p.r[k] = q[k];
+    for (int k = 0; k < 5; k++) p.r[k] = q[k];
+#pragma unroll
+    for (int k = 5; k < 8; k++) p.r[k] = make_float4(0, 0, 0, 0);
     return p;
+}
+PT_DEV uint32_t raw_packet_inst(const RawPacket& p) { return __float_as_uint(p.r[4].z); }
+// the second UV set and the vertex colours, for the meshes that have them
+PT_DEV void load_shade_packet_extra(RawPacket& p, const ShadePacket* pk) {
+    const float4* q = (const float4*)pk;
+#pragma unroll
+    for (int k = 5; k < 8; k++) p.r[k] = q[k];
 }
 PT_DEV PacketVerts unpack_shade_packet(const RawPacket& raw) {
     const float4* r = raw.r;
-    auto f = [&](int i) { const float4 v = r[i >> 2]; return (i & 3) == 0 ? v.x : ((i & 3) == 1 ? v.y : ((i & 3) == 2 ? v.z : v.w)); };
     PacketVerts o;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int b = 10 * k;
-        o.p[k] = v3(f(b), f(b + 1), f(b + 2));
-        o.ts[k] = __float_as_uint(f(b + 3));
-        o.uv0[k] = make_float2(f(b + 4), f(b + 5));
-        o.uv1[k] = make_float2(f(b + 6), f(b + 7));
-        o.col[k] = make_uint2(__float_as_uint(f(b + 8)), __float_as_uint(f(b + 9)));
-    }
-    o.inst = __float_as_uint(f(30));
+    for (int k = 0; k < 3; k++) { o.p[k] = v3(r[k].x, r[k].y, r[k].z); o.ts[k] = __float_as_uint(r[k].w); }
+    o.uv0[0] = make_float2(r[3].x, r[3].y); o.uv0[1] = make_float2(r[3].z, r[3].w); o.uv0[2] = make_float2(r[4].x, r[4].y);
+    o.inst = __float_as_uint(r[4].z);
+    o.uv1[0] = make_float2(r[5].x, r[5].y); o.uv1[1] = make_float2(r[5].z, r[5].w); o.uv1[2] = make_float2(r[6].x, r[6].y);
+    o.col[0] = make_uint2(__float_as_uint(r[6].z), __float_as_uint(r[6].w));
+    o.col[1] = make_uint2(__float_as_uint(r[7].x), __float_as_uint(r[7].y));
+    o.col[2] = make_uint2(__float_as_uint(r[7].z), __float_as_uint(r[7].w));
     return o;
 }
-PT_DEV PacketVerts load_shade_packet(const ShadePacket* pk) { return unpack_shade_packet(load_shade_packet_raw(pk)); }
+PT_DEV PacketVerts load_shade_packet(const ShadePacket* pk) { RawPacket p = load_shade_packet_raw(pk); load_shade_packet_extra(p, pk); return unpack_shade_packet(p); }   // the whole packet (any-hit alpha tests)
 PT_DEV vec4 fetch_vertex_color(bool present, const PacketVerts& pv, vec3 w) {                         // :229-242
     if (!present) return {1, 1, 1, 1};
     const uint2 q0 = pv.col[0], q1 = pv.col[1], q2 = pv.col[2];
@@ -706,17 +716,32 @@ PT_DEV vec3 gltf_bsdf(const float* lut, const Surface& s, vec3 v, vec3 l, int mo
     vec3 metal = refl ? v3(spec) * schlick3(s.albedo, hdv) : v3(0);                // ConductorFresnel :146-149
     vec3 material = lerp3(dielectric, metal, s.metalness);
     float sa = clampf(s.sheen_a, 0.000001f, 1);
-#ifndef PT_PROBE_BASE_ONLY
-    vec3 sheen = refl ? v3(saturate(ll.z) * sheen_brdf(sa, ll.z, vl.z, hl.z)) : v3(0);
-#else      // PROBE ONLY (tools/build_variant.sh): what the extension lobes cost a hit that has none; wrong for materials that do
-    vec3 sheen = v3(0);
-#endif
     float ms = max3(s.sheen_color);                                               // SheenMix :210-214
-    // Without sheen (ms == 0) both terms are 1 - 0 * E = 1 exactly (E is always finite: sheen_e clamps NaN coordinates):
-    // skip the eight table gathers.
-    float scaling = 1.0f;
-    if (ms != 0.0f) scaling = hmin(1.0f - ms * sheen_e(lut, sa, vl.z), 1.0f - ms * sheen_e(lut, sa, ll.z));
-    material = s.sheen_color * sheen + material * scaling;
+#ifndef PT_SHEEN_SKIP
+#define PT_SHEEN_SKIP 1
+#endif
+    // A material WITHOUT sheen (sheen colour exactly (0,0,0): every material that does not use KHR_materials_sheen) in a wave that holds no
+    // sheen material skips the sheen BRDF -- two pow, three SheenL, the exponentials: ~150 instructions, three evaluations a hit -- and gets
+    // the SAME bits: the layer term is 0 * sheen_brdf, which is +0 whenever sheen_brdf is finite and NaN otherwise, and sheen_brdf =
+    // saturate(.) * D * V with V clamped to [0, 1] (a NaN clamps to 0) and D = (2 + 1/a) pow(1 - ndh^2, 1/(2a)) / 2 pi, finite unless the pow's
+    // base is negative or NaN (|ndh| a rounding above 1, a NaN normal); the albedo scaling is 1 - 0 * E = 1 exactly.
+    const bool no_sheen = s.sheen_color.x == 0.0f && s.sheen_color.y == 0.0f && s.sheen_color.z == 0.0f;
+    if (PT_SHEEN_SKIP && !__any(!no_sheen)) {
+        const float sin2h = 1 - hl.z * hl.z;
+        const float layer = (refl && !(sin2h >= 0.0f)) ? __builtin_nanf("") : 0.0f;
+        material = v3(layer) + material * 1.0f;
+    } else {
+#ifndef PT_PROBE_BASE_ONLY
+        vec3 sheen = refl ? v3(saturate(ll.z) * sheen_brdf(sa, ll.z, vl.z, hl.z)) : v3(0);
+#else      // PROBE ONLY (tools/build_variant.sh): what the extension lobes cost a hit that has none; wrong for materials that do
+        vec3 sheen = v3(0);
+#endif
+        // Without sheen (ms == 0) both terms are 1 - 0 * E = 1 exactly (E is always finite: sheen_e clamps NaN coordinates):
+        // skip the eight table gathers.
+        float scaling = 1.0f;
+        if (ms != 0.0f) scaling = hmin(1.0f - ms * sheen_e(lut, sa, vl.z), 1.0f - ms * sheen_e(lut, sa, ll.z));
+        material = s.sheen_color * sheen + material * scaling;
+    }
     float cndv = dot(n, v), cndh = dot(n, h), cndl = dot(n, l);                    // (sic) shading normal
 #ifndef PT_PROBE_BASE_ONLY
     float cc = refl ? saturate(cndl) * specular_brdf(s.cc_rough, cndl, cndv, cndh, hdl, hdv) : 0.f;

@@ -153,9 +153,16 @@ static_assert(sizeof(TriPacket) == 48, "TriPacket");
 // three vertices, de-indexed at build time, so a hit reads ONE cache line instead of an index triple plus 9-15 scattered
 // 64-B sectors of the per-attribute streams (the shade stage moves ~4 TB/s of HBM traffic; this is a quarter of it).
 // Absent streams hold zeros; which streams exist is still told by the instance row's stream pointers.
+// The first 80 B (five dwordx4) hold what EVERY hit reads -- positions, packed tangent spaces, the first UV set, the instance id; the second
+// UV set and the vertex colours follow and are fetched only for meshes that have them (a dependent fetch for those meshes alone).  The
+// shade stage is bound by the number of divergent vector-memory instructions it issues (64 different lines each), not by their bytes:
+// three fewer per hit.
 struct __attribute__((aligned(128))) ShadePacket {
-    struct V { float pos[3]; uint32_t tangent_space; float uv0[2], uv1[2]; uint32_t color[2]; } v[3];   // 40 B each (object space)
+    struct V { float pos[3]; uint32_t tangent_space; } v[3];   // 48 B (object space)
+    float uv0[3][2];                // 24 B
     uint32_t inst, _pad;            // instance-table row (copy of TriPacket::inst: the shade stage never touches the TriPacket)
+    float uv1[3][2];                // 24 B  -- rarely present from here on
+    uint32_t color[3][2];           // 24 B
 };
 static_assert(sizeof(ShadePacket) == 128, "ShadePacket");
 

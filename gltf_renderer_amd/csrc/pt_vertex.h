@@ -51,21 +51,26 @@ extern __device__ unsigned long long pt_timing[12];
 #define PT_TICK(K)
 #define PT_TICK_FLUSH()
 #endif
-// `packet`: the hit triangle's shading packet (load_shade_packet_raw(sc.shade + hit.tri)), fetched by the caller so that it can be
-// in flight together with the caller's own fetches.
+// `packet_in`: the first 80 B of the hit triangle's shading packet (load_shade_packet_raw(packet_at)), fetched by the caller so that it can be
+// in flight together with the caller's own fetches; `packet_at` = where the rest is.
 // PRE: `pre` is the vertex's environment light sample, drawn ahead of time with this vertex's random numbers (wavefront pipeline:
 // the in-place code, its LDS tables and its registers are not compiled in); otherwise it is drawn here.
 template <bool PRE = false>
 PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint32_t seed, uint32_t px, uint32_t py, const Ray& ray, const HitRec& hit,
-                              const RawPacket& packet, PathState& ps, Followups& fu, unsigned& taps, const EnvSample* pre = nullptr) {
+                              const RawPacket& packet_in, const ShadePacket* packet_at, PathState& ps, Followups& fu, unsigned& taps, const EnvSample* pre = nullptr) {
     const uint32_t flags = fc.flags;
     fu.add = v3(0); fu.overwrite = false; fu.counted_shadow = 0;
     fu.q_env = fu.q_light = fu.q_bounce = false;
 #ifdef PT_TIMING
     unsigned long long _sec[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, _t = __builtin_readcyclecounter();
 #endif
-    const PacketVerts pv = unpack_shade_packet(packet);               // one 128-B line: the three vertices and the instance id
-    const ShadeInst inst = load_shade_inst(sc, pv.inst);
+    const ShadeInst inst = load_shade_inst(sc, raw_packet_inst(packet_in));
+    RawPacket packet = packet_in;
+    // the second UV set / vertex colours: a second fetch, only in waves that hold a hit on a mesh with either stream
+    if (__any((inst.streams & (SI_TEXCOORD1 | SI_COLOR)) != 0)) {
+        if (inst.streams & (SI_TEXCOORD1 | SI_COLOR)) load_shade_packet_extra(packet, packet_at);
+    }
+    const PacketVerts pv = unpack_shade_packet(packet);               // the three vertices and the instance id
     const RMat* mat = sc.rmats + inst.material_id;
     const MatHeader mh = material_header(sc, inst.material_id);
     HitGeom va = get_vertex_attributes(sc, inst, pv, v3(1 - hit.u - hit.v, hit.u, hit.v));

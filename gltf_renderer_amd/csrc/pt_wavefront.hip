@@ -51,15 +51,16 @@ constexpr int kCounterArrays = 7;
 
 struct WfBuffers {
     // per slot (one path per pixel of this rank)
-    float4* L;            // xyz radiance so far
+    float4* L;            // xyz radiance so far; w = bits: bit 0 env term pending, bit 1 light term pending
     float4* beta_pdf;     // beta.xyz, prev_pdf
     float4* thr_misc;     // thr.xyz, bits: rc | bounce << 16 | prev_mis << 31
-    float4* pend_env;     // xyz pending env-NEE term (beta-weighted), w = shadow transmission (written by the shadow stage)
-    float4* pend_light;   // same for the punctual-light term
-    uint32_t* pflags;     // bit 0 env pending, bit 1 light pending
+    float4* pend;         // [2 * slot] xyz pending env-NEE term (beta-weighted), w = its shadow transmission (written by the shadow stage);
+                          // [2 * slot + 1] the same for the punctual-light term: one 32-B piece per path
     // closest-ray queues (ping-pong), kShards segments of seg_cap entries: (o.xyz, tmax), (d.xyz, slot)
     float4* ray_o[2];
     float4* ray_d[2];
+    float4* q_beta[2];    // PT_BT_IN_QUEUE: the path's (beta, prev_pdf) and (throughput, misc bits) travel with its closest-ray entry -- written
+    float4* q_thr[2];     // compacted, read coalesced -- instead of living in the slot-indexed arrays beta_pdf / thr_misc above
     float4* hit;          // per entry of the current queue: t, u, v, bits: tri | front << 31 (kMissTri: miss)
     float4* env_a;        // per entry of the current closest queue: the vertex's environment light sample, drawn by the traversal stage that
     float4* env_b;        // traces the entry (env_prepass): (direction, pdf), (radiance, -)
@@ -120,6 +121,22 @@ PT_DEV uint32_t state_index(const WfBuffers& wf, uint32_t slot) {
 #endif
 }
 #define SIDX(s) state_index(wf, (s))
+#define PEND_ENV(s) wf.pend[2u * SIDX(s)]
+#define PEND_LIGHT(s) wf.pend[2u * SIDX(s) + 1u]
+// The random-sequence counter every path holds after its camera ray (camera_ray draws once): the state of a path at its FIRST vertex is a
+// constant -- L = 0, beta = 1, pdf = 0, throughput = 1, rc = kRcAfterCamera, nothing pending -- so the generate stage writes no state and
+// the first shade stage reads none (PT_FIRST_VERTEX_STATELESS).
+constexpr int kRcAfterCamera = 1;
+// The shade stage is bound by the divergent vector-memory instructions it issues (tools/pmc_shade_attribution.sh: taking the radiance /
+// pending records away -- 3 loads, 3 stores, 13 % of its fabric bytes -- made it 10 % faster).  beta / throughput are read by exactly one
+// consumer, the shade stage of the next vertex, which already reads the path's queue entry: with PT_BT_IN_QUEUE they ride in two more
+// arrays parallel to the closest-ray queue (coalesced both ways) instead of two slot-indexed arrays (a divergent load and store each).
+#ifndef PT_BT_IN_QUEUE
+#define PT_BT_IN_QUEUE 1
+#endif
+#ifndef PT_FIRST_VERTEX_STATELESS
+#define PT_FIRST_VERTEX_STATELESS 1
+#endif
 
 // wave64 ballot compaction into a shard counter: lanes with `pred` get consecutive indices; one atomic per wave.
 PT_DEV uint32_t queue_push(uint32_t* counter, bool pred) {
@@ -200,10 +217,16 @@ __global__ __launch_bounds__(kBlock) void k_wf_generate(FrameConstants fc, WfBuf
             const size_t e = (size_t)sv.shard * wf.seg_cap + idx;
             QST(wf.ray_o[0][e], make_float4(ray.o.x, ray.o.y, ray.o.z, ray.tmax));
             QST(wf.ray_d[0][e], make_float4(ray.d.x, ray.d.y, ray.d.z, __uint_as_float(slot)));
+#if !PT_FIRST_VERTEX_STATELESS
             SST(wf.L[SIDX(slot)], make_float4(0, 0, 0, 0));
+#if PT_BT_IN_QUEUE
+            QST(wf.q_beta[0][e], make_float4(1, 1, 1, 0));
+            QST(wf.q_thr[0][e], make_float4(1, 1, 1, __uint_as_float((uint32_t)rc)));
+#else
             SST(wf.beta_pdf[SIDX(slot)], make_float4(1, 1, 1, 0));
             SST(wf.thr_misc[SIDX(slot)], make_float4(1, 1, 1, __uint_as_float((uint32_t)rc)));
-            SST(wf.pflags[SIDX(slot)], 0);
+#endif
+#endif
             n_primary++;
         }
     }
@@ -295,7 +318,7 @@ PT_DEV void trace_persistent(const SceneRec& sc, const WfBuffers& wf, int* my_st
             } else {
                 const float tr = t.committed ? t.transmission : 1.0f;                                              // ShadowMiss :1081-1085
                 const uint32_t slot = slot_bits & 0x7fffffffu;
-                float* w = (slot_bits >> 31) ? &wf.pend_light[SIDX(slot)].w : &wf.pend_env[SIDX(slot)].w;
+                float* w = (slot_bits >> 31) ? &PEND_LIGHT(slot).w : &PEND_ENV(slot).w;
                 *w = tr;
             }
             has = false;
@@ -325,7 +348,7 @@ PT_DEV void trace_persistent(const SceneRec& sc, const WfBuffers& wf, int* my_st
 PT_DEV bool env_prepass_wanted(const SceneRec& sc, const FrameConstants& fc, int vertex_bounce) {
     return PT_ENV_PREPASS && sc.has_env && (fc.flags & PT_FLAG_ENVIRONMENT_MAP) && (fc.flags & PT_FLAG_ENVIRONMENT_MIS) && vertex_bounce < fc.max_bounces;
 }
-PT_DEV void env_prepass(const SceneRec& sc, const FrameConstants& fc, const WfBuffers& wf, int* stack_lds, const ShardView& sv, int cur) {
+PT_DEV void env_prepass(const SceneRec& sc, const FrameConstants& fc, const WfBuffers& wf, int* stack_lds, const ShardView& sv, int cur, bool first_vertex) {
     static_assert((size_t)kStackLds * kBlock * sizeof(int) >= (size_t)kImpLdsFloat4 * sizeof(float4), "the traversal stack's LDS must hold the importance pyramid's coarse levels");
     float4* top = (float4*)stack_lds;
     stage_importance_top_into(sc, top);
@@ -333,7 +356,12 @@ PT_DEV void env_prepass(const SceneRec& sc, const FrameConstants& fc, const WfBu
     const size_t base = (size_t)sv.shard * wf.seg_cap;
     for (uint32_t i = sv.member * kBlock + threadIdx.x; i < n; i += sv.stride) {
         const uint32_t slot = QLD(*((const uint32_t*)&wf.ray_d[cur][base + i] + 3));
-        int rc = (int)(SLD(*((const uint32_t*)&wf.thr_misc[SIDX(slot)] + 3)) & 0xffffu);
+        int rc = kRcAfterCamera;
+#if PT_BT_IN_QUEUE
+        if (!(PT_FIRST_VERTEX_STATELESS && first_vertex)) rc = (int)(QLD(*((const uint32_t*)&wf.q_thr[cur][base + i] + 3)) & 0xffffu);
+#else
+        if (!(PT_FIRST_VERTEX_STATELESS && first_vertex)) rc = (int)(SLD(*((const uint32_t*)&wf.thr_misc[SIDX(slot)] + 3)) & 0xffffu);
+#endif
         uint32_t px, py;
         slot_pixel(fc, slot, px, py);
         const vec4 r = next_random(px, py, sample_seed(fc, slot_sample(fc, slot)), rc);
@@ -359,7 +387,7 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_trace(SceneRec sc
     __shared__ int s_stack[kStackLds * kBlock];
     stage_luts(sc);
     const ShardView sv = shard_view(wf);
-    if (env_prepass_wanted(sc, fc, bounce)) env_prepass(sc, fc, wf, s_stack, sv, cur);
+    if (env_prepass_wanted(sc, fc, bounce)) env_prepass(sc, fc, wf, s_stack, sv, cur, bounce == 0);
     // member 0 of each shard zeroes the counters the following shade stage fills
     if (sv.member == 0 && threadIdx.x == 0) { wf.cnt[cur ^ 1][sv.shard * kCounterStride] = 0; wf.cnt[shadow_counter(bounce)][sv.shard * kCounterStride] = 0; wf.cnt[6][sv.shard * kCounterStride] = 0; }
     LaneStats st = {0, 0, 0, 0};
@@ -379,7 +407,7 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_traverse(SceneRec
     __shared__ int s_stack[kStackLds * kBlock];
     stage_luts(sc);
     const ShardView sv = shard_view(wf);
-    if (env_prepass_wanted(sc, fc, bounce + 1)) env_prepass(sc, fc, wf, s_stack, sv, nxt);
+    if (env_prepass_wanted(sc, fc, bounce + 1)) env_prepass(sc, fc, wf, s_stack, sv, nxt, false);
     if (sv.member == 0 && threadIdx.x == 0) { wf.cnt[nxt ^ 1][sv.shard * kCounterStride] = 0; wf.cnt[shadow_counter(bounce + 1)][sv.shard * kCounterStride] = 0; wf.cnt[6][sv.shard * kCounterStride] = 0; }
     LaneStats st_shadow = {0, 0, 0, 0}, st = {0, 0, 0, 0};
     trace_persistent<COUNT, 1>(sc, wf, s_stack + threadIdx.x, sv, shadow_counter(bounce), 0, 0xff, flags, st_shadow);
@@ -394,9 +422,9 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_traverse(SceneRec
 // the BSDF of an occluded sample: an occluded sample contributes nothing even when its pending term is NaN.
 // Both pending records are fetched whatever the flags say (the slots always exist): three loads in one round trip instead of
 // the flags first and the records behind them.
-PT_DEV void apply_pending(const WfBuffers& wf, uint32_t slot, vec3& L) {
-    const uint32_t pf = SLD(wf.pflags[SIDX(slot)]);
-    const float4 pe = SLD(wf.pend_env[SIDX(slot)]), pl = SLD(wf.pend_light[SIDX(slot)]);
+// `pf` = the pending bits that travel in L.w.
+PT_DEV void apply_pending(const WfBuffers& wf, uint32_t slot, uint32_t pf, vec3& L) {
+    const float4 pe = SLD(PEND_ENV(slot)), pl = SLD(PEND_LIGHT(slot));
     if ((pf & 1u) && pe.w > 0.0f) L += v3(pe.x, pe.y, pe.z) * pe.w;
     if ((pf & 2u) && pl.w > 0.0f) L += v3(pl.x, pl.y, pl.z) * pl.w;
 }
@@ -475,14 +503,29 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
             ray.o = v3(o.x, o.y, o.z); ray.tmin = 0; ray.d = v3(d.x, d.y, d.z); ray.tmax = o.w;
             // the hit's shading packet depends on the queue entry only, like the path state below: one round trip for both
             const uint32_t hb = __float_as_uint(h.w);
-            const RawPacket packet = load_shade_packet_raw(sc.shade + (hb == kMissTri ? 0u : (hb & 0x7fffffffu)));
-            const float4 bp = SLD(wf.beta_pdf[SIDX(slot)]), tm = SLD(wf.thr_misc[SIDX(slot)]);
-            const uint32_t misc = __float_as_uint(tm.w);
-            ps.beta = v3(bp.x, bp.y, bp.z); ps.prev_pdf = bp.w; ps.thr = v3(tm.x, tm.y, tm.z);
-            ps.rc = (int)(misc & 0xffffu); ps.bounce = (int)((misc >> 16) & 0x7fffu); ps.prev_mis = (misc >> 31) != 0;
-            float4 Lq = SLD(wf.L[SIDX(slot)]);
-            vec3 L = v3(Lq.x, Lq.y, Lq.z);
-            apply_pending(wf, slot, L);
+#ifdef PT_PROBE_NO_PACKET     // PROBE ONLY: every hit reads one of 64 packets -- wrong geometry, what the shading-packet gathers cost
+            const ShadePacket* packet_at = sc.shade + (hb == kMissTri ? 0u : (hb & 63u));
+#else
+            const ShadePacket* packet_at = sc.shade + (hb == kMissTri ? 0u : (hb & 0x7fffffffu));
+#endif
+            const RawPacket packet = load_shade_packet_raw(packet_at);
+            vec3 L = v3(0);
+            ps.beta = v3(1); ps.prev_pdf = 0; ps.thr = v3(1); ps.rc = kRcAfterCamera; ps.bounce = 0; ps.prev_mis = false;      // a path at its first vertex
+            if (!(PT_FIRST_VERTEX_STATELESS && bounce == 0)) {                  // (wave-uniform: `bounce` is a kernel argument)
+#if PT_BT_IN_QUEUE
+                const float4 bp = QLD(wf.q_beta[cur][base + i]), tm = QLD(wf.q_thr[cur][base + i]);
+#else
+                const float4 bp = SLD(wf.beta_pdf[SIDX(slot)]), tm = SLD(wf.thr_misc[SIDX(slot)]);
+#endif
+                const uint32_t misc = __float_as_uint(tm.w);
+                ps.beta = v3(bp.x, bp.y, bp.z); ps.prev_pdf = bp.w; ps.thr = v3(tm.x, tm.y, tm.z);
+                ps.rc = (int)(misc & 0xffffu); ps.bounce = (int)((misc >> 16) & 0x7fffu); ps.prev_mis = (misc >> 31) != 0;
+#ifndef PT_PROBE_NO_LP        // PROBE ONLY: the radiance and pending-term records are neither read nor written -- black image, same paths: what that class of state costs
+                const float4 Lq = SLD(wf.L[SIDX(slot)]);
+                L = v3(Lq.x, Lq.y, Lq.z);
+                apply_pending(wf, slot, __float_as_uint(Lq.w), L);
+#endif
+            }
             uint32_t pf = 0;
             if (hb == kMissTri) L += shade_miss(sc, fc, ray.d, ps);
             else {
@@ -492,21 +535,24 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
                 slot_pixel(fc, slot, px, py);
                 n_hits++;
 #if PT_ENV_PREPASS
-                const bool done = shade_closest_hit<true>(sc, fc, sample_seed(fc, slot_sample(fc, slot)), px, py, ray, hit, packet, ps, fu, st.taps, &es);
+                const bool done = shade_closest_hit<true>(sc, fc, sample_seed(fc, slot_sample(fc, slot)), px, py, ray, hit, packet, packet_at, ps, fu, st.taps, &es);
 #else
-                const bool done = shade_closest_hit(sc, fc, sample_seed(fc, slot_sample(fc, slot)), px, py, ray, hit, packet, ps, fu, st.taps);
+                const bool done = shade_closest_hit(sc, fc, sample_seed(fc, slot_sample(fc, slot)), px, py, ray, hit, packet, packet_at, ps, fu, st.taps);
 #endif
                 if (fu.overwrite) L = v3(0);
                 L += fu.add;
                 n_shadow += fu.counted_shadow;
                 if (!done) {
                     push_env = fu.q_env; push_light = fu.q_light; push_bounce = fu.q_bounce;
-                    if (push_env) { pf |= 1u; SST(wf.pend_env[SIDX(slot)], make_float4(fu.pend_env.x, fu.pend_env.y, fu.pend_env.z, 0.0f)); }
-                    if (push_light) { pf |= 2u; SST(wf.pend_light[SIDX(slot)], make_float4(fu.pend_light.x, fu.pend_light.y, fu.pend_light.z, 0.0f)); }
+#ifndef PT_PROBE_NO_LP
+                    if (push_env) { pf |= 1u; SST(PEND_ENV(slot), make_float4(fu.pend_env.x, fu.pend_env.y, fu.pend_env.z, 0.0f)); }
+                    if (push_light) { pf |= 2u; SST(PEND_LIGHT(slot), make_float4(fu.pend_light.x, fu.pend_light.y, fu.pend_light.z, 0.0f)); }
+#endif
                 }
             }
-            SST(wf.L[SIDX(slot)], make_float4(L.x, L.y, L.z, 0));
-            SST(wf.pflags[SIDX(slot)], pf);
+#ifndef PT_PROBE_NO_LP
+            SST(wf.L[SIDX(slot)], make_float4(L.x, L.y, L.z, __uint_as_float(pf)));
+#endif
         }
         // ---- compaction into this shard's shadow segment and next closest-ray segment (wave-uniform control flow)
         const uint32_t ie = queue_push(cnt_shadow, push_env);
@@ -525,9 +571,14 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
         if (push_bounce) {                                                                           // TraceBounceRay :669-678
             QST(wf.ray_o[nxt][base + ib], make_float4(fu.b_o.x, fu.b_o.y, fu.b_o.z, fc.max_ray_length));
             QST(wf.ray_d[nxt][base + ib], make_float4(fu.b_d.x, fu.b_d.y, fu.b_d.z, __uint_as_float(slot)));
-            SST(wf.beta_pdf[SIDX(slot)], make_float4(fu.b_beta.x, fu.b_beta.y, fu.b_beta.z, fu.b_pdf));
             const uint32_t misc = ((uint32_t)ps.rc & 0xffffu) | ((uint32_t)(ps.bounce + 1) << 16) | (fu.b_mis ? 0x80000000u : 0u);
+#if PT_BT_IN_QUEUE
+            QST(wf.q_beta[nxt][base + ib], make_float4(fu.b_beta.x, fu.b_beta.y, fu.b_beta.z, fu.b_pdf));
+            QST(wf.q_thr[nxt][base + ib], make_float4(fu.b_thr.x, fu.b_thr.y, fu.b_thr.z, __uint_as_float(misc)));
+#else
+            SST(wf.beta_pdf[SIDX(slot)], make_float4(fu.b_beta.x, fu.b_beta.y, fu.b_beta.z, fu.b_pdf));
             SST(wf.thr_misc[SIDX(slot)], make_float4(fu.b_thr.x, fu.b_thr.y, fu.b_thr.z, __uint_as_float(misc)));
+#endif
             n_bounce++;
         }
 #if PT_SHADE_DYNAMIC
@@ -563,7 +614,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_resolve(FrameConstants fc, WfBuff
         const uint32_t slot = k * fc.pixel_slots + pslot;
         float4 Lq = SLD(wf.L[SIDX(slot)]);
         vec3 L = v3(Lq.x, Lq.y, Lq.z);
-        apply_pending(wf, slot, L);
+        apply_pending(wf, slot, __float_as_uint(Lq.w), L);
         L = sanitize_sample(fc, L);
         const int accumulated = fc.accumulated_frames + (int)k;
         pixel = (accumulate && accumulated != 0) ? blend_sample(pixel, accumulated, L) : make_float4(L.x, L.y, L.z, 1.0f);
@@ -601,7 +652,7 @@ size_t wavefront_workspace_bytes(const FrameConstants& fc, int stage_blocks) {
     const uint32_t bps = blocks_per_shard_for(stage_blocks);
     const size_t slots = state_slots_for((size_t)fc.my_tiles * kBlock * fc.spp);
     const size_t q = (size_t)kShards * seg_cap_for(fc, bps);
-    return slots * (5 * 16 + 4) + q * (4 * 16 + 16 + 2 * 16 + 2 * 2 * 16) + kCounterArrays * kShards * kCounterStride * 4 + 32 * 256;
+    return slots * (5 * 16) + q * (4 * 16 + 4 * 16 + 16 + 2 * 16 + 2 * 2 * 16) + kCounterArrays * kShards * kCounterStride * 4 + 48 * 256;
 }
 
 static WfBuffers carve(void* base, const FrameConstants& fc, int stage_blocks) {
@@ -620,10 +671,9 @@ static WfBuffers carve(void* base, const FrameConstants& fc, int stage_blocks) {
     wf.L = (float4*)take(state_slots * 16);
     wf.beta_pdf = (float4*)take(state_slots * 16);
     wf.thr_misc = (float4*)take(state_slots * 16);
-    wf.pend_env = (float4*)take(state_slots * 16);
-    wf.pend_light = (float4*)take(state_slots * 16);
-    wf.pflags = (uint32_t*)take(state_slots * 4);
+    wf.pend = (float4*)take(state_slots * 32);
     for (int k = 0; k < 2; k++) { wf.ray_o[k] = (float4*)take(q * 16); wf.ray_d[k] = (float4*)take(q * 16); }
+    for (int k = 0; k < 2; k++) { wf.q_beta[k] = (float4*)take(q * 16); wf.q_thr[k] = (float4*)take(q * 16); }
     wf.hit = (float4*)take(q * 16);
     wf.env_a = (float4*)take(q * 16);
     wf.env_b = (float4*)take(q * 16);

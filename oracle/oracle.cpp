@@ -209,8 +209,10 @@ static void tri_bounds(const Tri& t, float3& lo, float3& hi) {
     float3 a = t.v0, b = t.v0 + t.e1, c = t.v0 + t.e2;
     lo = hmin(hmin(a, b), c); hi = hmax(hmax(a, b), c);
 }
-// returns child reference; fills bounds
-static int build_range(BuildCtx& c, int first, int last, float3& lo, float3& hi) {
+// returns child reference; fills bounds.  `idx` = the node's index: the tree is numbered in pre-order (a range of k triangles has k - 1
+// inner nodes, so the left child of node idx is idx + 1 and the right child idx + 1 + (split - first)), which is the order the recursion
+// visits them in -- and what lets subtrees be built by different threads into one pre-sized array with the SAME numbering.
+static int build_range(BuildCtx& c, int first, int last, int idx, float3& lo, float3& hi) {
     if (first == last) { tri_bounds((*c.tris)[first], lo, hi); return ~first; }
     const auto& k = *c.keys;
     int cp = common_prefix(k, first, last);
@@ -220,44 +222,134 @@ static int build_range(BuildCtx& c, int first, int last, float3& lo, float3& hi)
         int ns = split + step;
         if (ns < last && common_prefix(k, first, ns) > cp) split = ns;
     } while (step > 1);
-    int idx = (int)c.nodes->size();
-    c.nodes->push_back(BNode());
     float3 l0, h0, l1, h1;
-    int c0 = build_range(c, first, split, l0, h0);
-    int c1 = build_range(c, split + 1, last, l1, h1);
+    int c0 = build_range(c, first, split, idx + 1, l0, h0);
+    int c1 = build_range(c, split + 1, last, idx + 1 + (split - first), l1, h1);
     BNode& n = (*c.nodes)[idx];
     n.lo[0] = l0; n.hi[0] = h0; n.lo[1] = l1; n.hi[1] = h1; n.child[0] = c0; n.child[1] = c1;
     lo = hmin(l0, l1); hi = hmax(h0, h1);
     return idx;
 }
-static void build_lbvh(Bvh& bvh) {
+// The same range, its subtrees of at most `grain` triangles handed to `tasks` instead of being descended into (their boxes are filled in
+// by the second pass below once the tasks have run).
+struct SubtreeTask { int first, last, idx; float3 lo, hi; };
+static int split_of(const std::vector<uint64_t>& k, int first, int last) {
+    int cp = common_prefix(k, first, last);
+    int split = first, step = last - first;
+    do {
+        step = (step + 1) >> 1;
+        int ns = split + step;
+        if (ns < last && common_prefix(k, first, ns) > cp) split = ns;
+    } while (step > 1);
+    return split;
+}
+static void collect_tasks(BuildCtx& c, int first, int last, int idx, int grain, std::vector<SubtreeTask>& tasks) {
+    if (first == last || last - first + 1 <= grain) { tasks.push_back({first, last, idx, {}, {}}); return; }
+    int split = split_of(*c.keys, first, last);
+    collect_tasks(c, first, split, idx + 1, grain, tasks);
+    collect_tasks(c, split + 1, last, idx + 1 + (split - first), grain, tasks);
+}
+static int finish_top(BuildCtx& c, int first, int last, int idx, int grain, const std::vector<SubtreeTask>& tasks, size_t& next, float3& lo, float3& hi) {
+    if (first == last || last - first + 1 <= grain) {
+        const SubtreeTask& t = tasks[next++];
+        lo = t.lo; hi = t.hi;
+        return first == last ? ~first : idx;
+    }
+    int split = split_of(*c.keys, first, last);
+    float3 l0, h0, l1, h1;
+    int c0 = finish_top(c, first, split, idx + 1, grain, tasks, next, l0, h0);
+    int c1 = finish_top(c, split + 1, last, idx + 1 + (split - first), grain, tasks, next, l1, h1);
+    BNode& n = (*c.nodes)[idx];
+    n.lo[0] = l0; n.hi[0] = h0; n.lo[1] = l1; n.hi[1] = h1; n.child[0] = c0; n.child[1] = c1;
+    lo = hmin(l0, l1); hi = hmax(h0, h1);
+    return idx;
+}
+template <class F> static void parallel_chunks(size_t n, int nthreads, F f) {        // f(begin, end, chunk index)
+    if (nthreads <= 1 || n < 4096) { f((size_t)0, n, 0); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++) th.emplace_back([=]() { f(n * t / nthreads, n * (t + 1) / nthreads, t); });
+    for (auto& t : th) t.join();
+}
+// nthreads <= 1: the single-threaded build every parity test runs.  nthreads > 1: the same tree, node for node (same Morton codes, a
+// stable sort by chunks + stable merges, pre-order numbering), built on that many cores -- bench.py's cpu_baseline leg B2.
+static void build_lbvh(Bvh& bvh, int nthreads = 1) {
+    const bool prof = getenv("ORC_PROFILE") != nullptr;
+    auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (prof) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  lbvh %-10s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tp).count()); tp = t; } };
     size_t n = bvh.tris.size();
     bvh.nodes.clear();
     if (n == 0) { bvh.root = 0; return; }
-    float3 clo = F3(INFINITY), chi = F3(-INFINITY);
     std::vector<float3> cen(n);
-    for (size_t i = 0; i < n; i++) {
-        float3 lo, hi; tri_bounds(bvh.tris[i], lo, hi);
-        cen[i] = (lo + hi) * 0.5f;
-        clo = hmin(clo, cen[i]); chi = hmax(chi, cen[i]);
-    }
+    const int T = std::max(1, nthreads);
+    std::vector<float3> plo((size_t)T, F3(INFINITY)), phi((size_t)T, F3(-INFINITY));
+    parallel_chunks(n, T, [&](size_t b, size_t e, int t) {
+        float3 clo = F3(INFINITY), chi = F3(-INFINITY);
+        for (size_t i = b; i < e; i++) {
+            float3 lo, hi; tri_bounds(bvh.tris[i], lo, hi);
+            cen[i] = (lo + hi) * 0.5f;
+            clo = hmin(clo, cen[i]); chi = hmax(chi, cen[i]);
+        }
+        plo[(size_t)t] = clo; phi[(size_t)t] = chi;
+    });
+    float3 clo = F3(INFINITY), chi = F3(-INFINITY);
+    for (int t = 0; t < T; t++) { clo = hmin(clo, plo[(size_t)t]); chi = hmax(chi, phi[(size_t)t]); }
     float3 ext = chi - clo;
+    lap("bounds");
     std::vector<std::pair<uint64_t, uint32_t>> keyed(n);
-    for (size_t i = 0; i < n; i++) {
-        float3 q = (cen[i] - clo) / hmax(ext, F3(1e-30f));
-        uint64_t x = (uint64_t)clamp(q.x * 2097152.f, 0.f, 2097151.f), y = (uint64_t)clamp(q.y * 2097152.f, 0.f, 2097151.f),
-                 z = (uint64_t)clamp(q.z * 2097152.f, 0.f, 2097151.f);
-        keyed[i] = {expand21(x) << 2 | expand21(y) << 1 | expand21(z), (uint32_t)i};
+    auto by_key = [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& b) { return a.first < b.first; };
+    std::vector<size_t> cut;
+    parallel_chunks(n, T, [&](size_t b, size_t e, int) {
+        for (size_t i = b; i < e; i++) {
+            float3 q = (cen[i] - clo) / hmax(ext, F3(1e-30f));
+            uint64_t x = (uint64_t)clamp(q.x * 2097152.f, 0.f, 2097151.f), y = (uint64_t)clamp(q.y * 2097152.f, 0.f, 2097151.f),
+                     z = (uint64_t)clamp(q.z * 2097152.f, 0.f, 2097151.f);
+            keyed[i] = {expand21(x) << 2 | expand21(y) << 1 | expand21(z), (uint32_t)i};
+        }
+        std::stable_sort(keyed.begin() + (ptrdiff_t)b, keyed.begin() + (ptrdiff_t)e, by_key);
+    });
+    lap("sort");
+    if (T > 1 && n >= 4096) {                                         // stable pairwise merges of the sorted chunks, a round per doubling
+        for (int t = 0; t <= T; t++) cut.push_back(n * (size_t)t / (size_t)T);
+        while (cut.size() > 2) {
+            std::vector<std::thread> th;
+            std::vector<size_t> nc;
+            for (size_t k = 0; k + 2 < cut.size() + 1 && k + 1 < cut.size(); k += 2) {
+                const size_t a = cut[k], m = cut[k + 1], e = k + 2 < cut.size() ? cut[k + 2] : cut[k + 1];
+                nc.push_back(a);
+                if (e > m) th.emplace_back([&keyed, a, m, e, by_key]() { std::inplace_merge(keyed.begin() + (ptrdiff_t)a, keyed.begin() + (ptrdiff_t)m, keyed.begin() + (ptrdiff_t)e, by_key); });
+            }
+            nc.push_back(n);
+            for (auto& t : th) t.join();
+            cut.swap(nc);
+        }
     }
-    std::stable_sort(keyed.begin(), keyed.end(), [](auto& a, auto& b) { return a.first < b.first; });
+    lap("merge");
     std::vector<Tri> sorted(n);
     std::vector<uint64_t> keys(n);
-    for (size_t i = 0; i < n; i++) { sorted[i] = bvh.tris[keyed[i].second]; keys[i] = keyed[i].first; }
+    parallel_chunks(n, T, [&](size_t b, size_t e, int) { for (size_t i = b; i < e; i++) { sorted[i] = bvh.tris[keyed[i].second]; keys[i] = keyed[i].first; } });
     bvh.tris.swap(sorted);
-    bvh.nodes.reserve(n);
+    bvh.nodes.assign(n > 1 ? n - 1 : 0, BNode());
     BuildCtx c{&keys, &bvh.nodes, &bvh.tris};
     float3 lo, hi;
-    bvh.root = build_range(c, 0, (int)n - 1, lo, hi);
+    lap("gather");
+    if (T <= 1 || n < 4096) { bvh.root = build_range(c, 0, (int)n - 1, 0, lo, hi); lap("tree"); return; }
+    std::vector<SubtreeTask> tasks;
+    const int grain = (int)std::max<size_t>(256, n / ((size_t)T * 8));
+    collect_tasks(c, 0, (int)n - 1, 0, grain, tasks);
+    std::atomic<size_t> next_task{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++) th.emplace_back([&]() {
+        for (;;) {
+            size_t k = next_task.fetch_add(1);
+            if (k >= tasks.size()) break;
+            BuildCtx cc = c;
+            build_range(cc, tasks[k].first, tasks[k].last, tasks[k].idx, tasks[k].lo, tasks[k].hi);
+        }
+    });
+    for (auto& t : th) t.join();
+    size_t next = 0;
+    bvh.root = finish_top(c, 0, (int)n - 1, 0, grain, tasks, next, lo, hi);
+    lap("tree");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -843,26 +935,48 @@ static bool mat4_inverse(const float* mf, float* out) {
 }
 
 // BuildAllBlas + BuildTlas restated as one world-space triangle soup (Pathtracer.cpp:138-257)
-static void build_accel(Oracle& o) {
+static void build_accel(Oracle& o, int nthreads = 1) {
     auto t0 = std::chrono::steady_clock::now();
-    o.bvh.tris.clear();
-    for (size_t ii = 0; ii < o.instances.size(); ii++) {
-        const InstanceDesc& id = o.instances[ii];
-        const Instance& in = id.gpu;
-        uint32_t ntri = id.num_of_indices / 3;
-        const float* M = in.transform.m;
-        double det = (double)M[0] * ((double)M[5] * M[10] - (double)M[9] * M[6]) - (double)M[4] * ((double)M[1] * M[10] - (double)M[9] * M[2]) +
-                     (double)M[8] * ((double)M[1] * M[6] - (double)M[5] * M[2]);
-        for (uint32_t p = 0; p < ntri; p++) {
-            uint32_t v[3];
-            GetIndices(o, in.index_descriptor, p, v);
-            float3 w[3];
-            for (int k = 0; k < 3; k++) w[k] = xyz(mul(in.transform, F4(fetch_pos(o, in.position_descriptor, v[k]), 1)));
-            Tri t; t.v0 = w[0]; t.e1 = w[1] - w[0]; t.e2 = w[2] - w[0]; t.inst = (uint32_t)ii; t.prim = p; t.flags = det < 0 ? 1u : 0u;
-            o.bvh.tris.push_back(t);
+    std::vector<size_t> first(o.instances.size() + 1, 0);
+    for (size_t ii = 0; ii < o.instances.size(); ii++) first[ii + 1] = first[ii] + o.instances[ii].num_of_indices / 3;
+    o.bvh.tris.assign(first.back(), Tri());
+    std::atomic<size_t> next_chunk{0};
+    const size_t kChunk = 4096;                            // triangles per unit of work: (instance, range) pairs found by a search in `first`
+    const size_t n_chunks = (first.back() + kChunk - 1) / kChunk;
+    auto fill = [&]() {
+        for (;;) {
+            const size_t ck = next_chunk.fetch_add(1);
+            if (ck >= n_chunks) break;
+            const size_t b = ck * kChunk, e = std::min(first.back(), b + kChunk);
+            size_t ii = (size_t)(std::upper_bound(first.begin(), first.end(), b) - first.begin()) - 1;
+            for (size_t g = b; g < e; ) {
+                while (first[ii + 1] <= g) ii++;
+                const InstanceDesc& id = o.instances[ii];
+                const Instance& in = id.gpu;
+                const float* M = in.transform.m;
+                double det = (double)M[0] * ((double)M[5] * M[10] - (double)M[9] * M[6]) - (double)M[4] * ((double)M[1] * M[10] - (double)M[9] * M[2]) +
+                             (double)M[8] * ((double)M[1] * M[6] - (double)M[5] * M[2]);
+                const size_t stop = std::min(e, first[ii + 1]);
+                for (; g < stop; g++) {
+                    const uint32_t p = (uint32_t)(g - first[ii]);
+                    uint32_t v[3];
+                    GetIndices(o, in.index_descriptor, p, v);
+                    float3 w[3];
+                    for (int k = 0; k < 3; k++) w[k] = xyz(mul(in.transform, F4(fetch_pos(o, in.position_descriptor, v[k]), 1)));
+                    Tri t; t.v0 = w[0]; t.e1 = w[1] - w[0]; t.e2 = w[2] - w[0]; t.inst = (uint32_t)ii; t.prim = p; t.flags = det < 0 ? 1u : 0u;
+                    o.bvh.tris[g] = t;
+                }
+            }
         }
+    };
+    if (nthreads <= 1) fill();
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; t++) th.emplace_back(fill);
+        for (auto& t : th) t.join();
     }
-    build_lbvh(o.bvh);
+    if (getenv("ORC_PROFILE")) fprintf(stderr, "  flatten %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    build_lbvh(o.bvh, nthreads);
     o.accel_dirty = false;
     o.last_accel_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -1158,6 +1272,8 @@ void orc_env_read(void* h, int env, uint16_t* cube_rgba16f, float* pyramid) {
 void orc_set_bounce_limit(void* h, int limit) { ((Oracle*)h)->bounce_limit = limit; }
 void orc_set_brute_force(void* h, int on) { ((Oracle*)h)->brute_force = on != 0; }
 void orc_build_accel(void* h) { build_accel(*(Oracle*)h); }
+// the same tree built on `nthreads` cores (bench.py cpu_baseline leg B2); 1 = the build above
+void orc_build_accel_mt(void* h, int nthreads) { build_accel(*(Oracle*)h, nthreads); }
 void orc_skin_run(void* h, const void* params, const void* bones, int bone_count) { skin_run(*(Oracle*)h, *(const SkinParams*)params, (const Bone*)bones, bone_count); }
 void orc_trace(void* h, const void* settings, const void* params, int nthreads) { pathtrace_scene(*(Oracle*)h, *(const Settings*)settings, *(const ExecuteParams*)params, nthreads); }
 // out[0..6] = primary, bounce, shadow, nodes, tris, closest hits, texture taps; out[7] = accumulated_frames

@@ -32,6 +32,8 @@ def lib():
         for name in ("orc_destroy", "orc_build_accel"):
             getattr(L, name).argtypes = [C.c_void_p]
             getattr(L, name).restype = None
+        L.orc_build_accel_mt.argtypes = [C.c_void_p, C.c_int]
+        L.orc_build_accel_mt.restype = None
         L.orc_buffer_create.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         L.orc_buffer_update.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.orc_buffer_read.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
@@ -182,8 +184,12 @@ class Oracle:
     def set_brute_force(self, on):
         self.L.orc_set_brute_force(self.h, int(on))
 
-    def build_accel(self):
-        self.L.orc_build_accel(self.h)
+    def build_accel(self, nthreads=1):
+        """CPU LBVH of the scene; nthreads > 1 builds the SAME tree (node for node) on that many cores."""
+        if nthreads and nthreads > 1:
+            self.L.orc_build_accel_mt(self.h, int(nthreads))
+        else:
+            self.L.orc_build_accel(self.h)
 
     def skin_run(self, params, bones):
         if bones is None or len(bones) == 0:

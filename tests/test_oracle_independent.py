@@ -499,3 +499,24 @@ def test_pick_morph_targets_rule():
     assert [t for t, _ in scenes.pick_morph_targets([0.1, 0.2, 0.3, 0.4, 0.05])] == [0, 1, 2, 3]          # smaller than every held weight
     assert [t for t, _ in scenes.pick_morph_targets([0.1, 0.2, 0.3, 0.4, 0.5])] == [4, 1, 2, 3]           # replaces the smallest
     assert [t for t, _ in scenes.pick_morph_targets([0.3, 0.1, 0.1, 0.4, 0.2, 0.25])] == [0, 4, 5, 3]     # first of equal minima first
+
+
+def test_multi_threaded_cpu_lbvh_is_the_single_threaded_tree(oracle_lib):
+    """bench.py's cpu_baseline times the CPU LBVH build on one core and on all of them (leg B2): the parallel build
+    (chunk sorts + stable merges, subtrees built by different threads into one pre-order-numbered array) must be the SAME tree -- same node
+    and triangle-test counts for the same rays, same image bit for bit."""
+    s = scenes.sponza_class(width=64, height=36, tex=16)
+    st = abi.PtSettings.from_buffer_copy(bytes(s.settings)); st.flags &= ~abi.FLAG_ACCUMULATE; st.use_frame_as_seed = 0; st.seed = 5
+    res = []
+    for threads in (1, 8, 3):
+        o = oracle_lib.Oracle(); h = s.upload(o)
+        o.build_accel(threads)
+        img = np.zeros((s.height, s.width, 4), np.float32)
+        o.counters()
+        o.trace(st, s.execute_params(0, env_handle=h["env"]), img, nthreads=4)
+        c = o.counters()
+        res.append((img, c["nodes"], c["tris"], c["rays"], o.bvh_info()))
+        o.close()
+    for img, nodes, tris, rays, info in res[1:]:
+        assert np.array_equal(img, res[0][0]) and (nodes, tris, rays, info) == res[0][1:]
+    assert res[0][4][1] > 200000                                     # the bench scene's triangle count, not a toy
