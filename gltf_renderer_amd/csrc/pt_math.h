@@ -54,8 +54,8 @@ PT_DEV vec3 xyz(vec4 v) { return {v.x, v.y, v.z}; }
 // BIT-IDENTICAL to a / b whenever divisor, dividend and quotient are normal numbers (tools/probes/lean_div_probe.hip: 0 mismatches in
 // 8.4e9 random operand pairs over exponents -60..60).  OUTSIDE that contract it is not IEEE division: a quotient below 2^-126 is not
 // correctly rounded, and -- because nothing rescales the operands -- a quotient that OVERFLOWS (q = a * r = inf, then fma(-b, inf, a) = -inf
-// and fma(-inf, r, inf) = NaN) and a SUBNORMAL divisor (v_rcp gives inf, the correction of the reciprocal NaN) both return NaN where a / b is
-// +-inf or a large finite number; v_div_fixup only repairs zero / infinite / NaN OPERANDS.  On the path that reaches contrib / light_pdf,
+// and fma(-inf, r, inf) = NaN) returns NaN where a / b is +-inf, and a SUBNORMAL divisor (v_rcp gives inf) returns NaN or +-inf where a / b is a
+// large finite number; v_div_fixup only repairs zero / infinite / NaN OPERANDS.  On the path that reaches contrib / light_pdf,
 // the MIS ratios and the luminance clamp, sanitize_sample zeroes a NaN and an Inf sample alike (PathTracer.lib.hlsl:760-766), so images do
 // not change; FLAG_SHOW_NAN / FLAG_SHOW_INF would paint such a sample red under the other flag.  tools/probes/lean_div_probe.hip prints
 // the cases, tests/test_gpu_math.py pins them.  Where those operands can occur by construction (1 / direction of the ray set-up) the code

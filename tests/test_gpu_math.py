@@ -35,10 +35,10 @@ def test_shortened_division_matches_the_ieee_quotient_on_normal_operands(tmp_pat
     as_f = lambda t: float(t.replace("-nan", "nan"))
     for i in (0, 1, 2):                                    # overflow
         assert as_f(sp[i][1]) in (float("inf"), float("-inf")) and (as_f(sp[i][0]) != as_f(sp[i][0]) or as_f(sp[i][0]) == as_f(sp[i][1])), sp[i]
-    for i in (3, 4, 5):                                    # subnormal divisor
+    print("fdiv outside its contract (fdiv, ieee):", sp)
+    for i in (3, 4, 5):                                    # subnormal divisor: the reciprocal is infinite, the result NaN or +-inf (IEEE: large and finite, or inf)
         l, e = as_f(sp[i][0]), as_f(sp[i][1])
-        assert l != l or l == e, sp[i]
+        assert l != l or abs(l) == float("inf") or l == e, sp[i]
     for i in (6, 8, 9):                                    # x / 0, x / inf, inf / x: the same as IEEE
         assert as_f(sp[i][0]) == as_f(sp[i][1]), sp[i]
     assert as_f(sp[7][0]) != as_f(sp[7][0]) and as_f(sp[7][1]) != as_f(sp[7][1])          # 0 / 0
-    print("fdiv outside its contract:", sp)
