@@ -52,14 +52,13 @@ PT_DEV vec3 xyz(vec4 v) { return {v.x, v.y, v.z}; }
 // that part from the oracle and broke the exact white furnace).  fdiv() is the same Newton-Raphson core without the operand scaling:
 // rcp, one correction of the reciprocal, one of the quotient, then v_div_fixup for the special operands (zero, infinity, NaN).  It is
 // BIT-IDENTICAL to a / b whenever divisor, dividend and quotient are normal numbers (tools/probes/lean_div_probe.hip: 0 mismatches in
-// 8.4e9 random operand pairs over exponents -60..60).  OUTSIDE that contract it is not IEEE division: a quotient below 2^-126 is not
-// correctly rounded, and -- because nothing rescales the operands -- a quotient that OVERFLOWS (q = a * r = inf, then fma(-b, inf, a) = -inf
-// and fma(-inf, r, inf) = NaN) returns NaN where a / b is +-inf, and a SUBNORMAL divisor (v_rcp gives inf) returns NaN or +-inf where a / b is a
-// large finite number; v_div_fixup only repairs zero / infinite / NaN OPERANDS.  On the path that reaches contrib / light_pdf,
-// the MIS ratios and the luminance clamp, sanitize_sample zeroes a NaN and an Inf sample alike (PathTracer.lib.hlsl:760-766), so images do
-// not change; FLAG_SHOW_NAN / FLAG_SHOW_INF would paint such a sample red under the other flag.  tools/probes/lean_div_probe.hip prints
-// the cases, tests/test_gpu_math.py pins them.  Where those operands can occur by construction (1 / direction of the ray set-up) the code
-// keeps the compiler's sequence.
+// 8.4e9 random operand pairs over exponents -60..60).  OUTSIDE that contract it is not IEEE division, because nothing rescales the operands: a
+// quotient below 2^-126 is not correctly rounded, and a SUBNORMAL divisor (v_rcp treats it as zero: the reciprocal is infinite) returns +-inf
+// where a / b is a large finite number (1e-30 / 1e-39: inf for 1e9).  A quotient that overflows comes out +-inf like a / b, and zero, infinite
+// and NaN operands are repaired by v_div_fixup (measured on the MI355X: tools/probes/lean_div_probe.hip prints the cases,
+// tests/test_gpu_math.py pins them).  On the path that reaches contrib / light_pdf, the MIS ratios and the luminance clamp a subnormal pdf is
+// already a degenerate sample that sanitize_sample zeroes either way (NaN and Inf alike, PathTracer.lib.hlsl:760-766).  Where such operands
+// can occur by construction (1 / direction of the ray set-up) the code keeps the compiler's sequence.
 // A vector divided by one scalar corrects the reciprocal once.  PT_EXACT_DIV=1 restores the compiler's sequence everywhere (A/B).
 #ifndef PT_EXACT_DIV
 #define PT_EXACT_DIV 0

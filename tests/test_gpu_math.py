@@ -28,17 +28,15 @@ def test_shortened_division_matches_the_ieee_quotient_on_normal_operands(tmp_pat
             assert int(bad) == 0, (lo, hi, bad)
             checked += float(pairs)
     assert checked >= 8e9, checked
-    # outside the contract, pinned so that the comment in pt_math.h stays true: an overflowing quotient and a subnormal divisor
-    # give NaN (IEEE: +-inf / a large finite number); zero, infinite and NaN operands are repaired by v_div_fixup like the IEEE sequence
+    # outside the contract, pinned so that the comment in pt_math.h stays true: an overflowing quotient is +-inf like a / b, zero /
+    # infinite / NaN operands are repaired by v_div_fixup, and a subnormal divisor gives +-inf (or NaN) where IEEE gives a large finite number
     sp = {int(i): (l, e) for i, l, e in re.findall(r"special (\d+): .* -> fdiv (\S+) , ieee (\S+)", out)}
     assert len(sp) == 10, out
     as_f = lambda t: float(t.replace("-nan", "nan"))
-    for i in (0, 1, 2):                                    # overflow
-        assert as_f(sp[i][1]) in (float("inf"), float("-inf")) and (as_f(sp[i][0]) != as_f(sp[i][0]) or as_f(sp[i][0]) == as_f(sp[i][1])), sp[i]
     print("fdiv outside its contract (fdiv, ieee):", sp)
-    for i in (3, 4, 5):                                    # subnormal divisor: the reciprocal is infinite, the result NaN or +-inf (IEEE: large and finite, or inf)
+    for i in (0, 1, 2, 6, 8, 9):                           # overflow, x / 0, x / inf, inf / x: the same as IEEE
+        assert as_f(sp[i][0]) == as_f(sp[i][1]), (i, sp[i])
+    for i in (3, 4, 5):                                    # subnormal divisor
         l, e = as_f(sp[i][0]), as_f(sp[i][1])
         assert l != l or abs(l) == float("inf") or l == e, sp[i]
-    for i in (6, 8, 9):                                    # x / 0, x / inf, inf / x: the same as IEEE
-        assert as_f(sp[i][0]) == as_f(sp[i][1]), sp[i]
     assert as_f(sp[7][0]) != as_f(sp[7][0]) and as_f(sp[7][1]) != as_f(sp[7][1])          # 0 / 0
