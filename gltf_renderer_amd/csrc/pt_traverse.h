@@ -64,6 +64,7 @@ struct Trav {
     int mode;                  // 0 closest hit, 1 occlusion
     bool all_candidates;       // alpha-shadow rays visit every candidate of the ORIGINAL interval (quirk q12)
     int cur, sp;
+    int post;                  // a leaf this lane reached but has not tested yet (kTravDone: none): trace_persistent's postponed leaf
     HitRec best;
     float transmission;        // ShadowPayload
     bool committed;
@@ -85,6 +86,7 @@ PT_DEV void trav_init(Trav& t, const SceneRec& sc, const Ray& r, uint32_t rf, ui
     t.transmission = transmission0;
     t.committed = false;
     t.sp = 0;
+    t.post = kTravDone;
     t.cur = (mask == 0 || sc.num_tris == 0) ? kTravDone : sc.root;
 }
 
@@ -254,8 +256,10 @@ PT_DEV void trav_node_step(Trav& t, const SceneRec& sc, int* lds_stack, int* spi
 #endif
 
 // One leaf step: t.cur = leaf reference (1..kLeafMax contiguous triangles) on entry; on exit the popped entry or kTravDone.
+// `keep` != kTravDone: the leaf tested is a POSTPONED one (trace_persistent): instead of popping, the lane goes on with `keep`, the entry it
+// had already moved on to -- unless the ray ended in this leaf.
 template <bool COUNT>
-PT_DEV void trav_leaf_step(Trav& t, const SceneRec& sc, const int* lds_stack, const int* spill, LaneStats& st) {
+PT_DEV void trav_leaf_step(Trav& t, const SceneRec& sc, const int* lds_stack, const int* spill, LaneStats& st, bool keep_next = false, int keep = kTravDone) {
     const uint32_t leaf = (uint32_t)~t.cur;
     const int first = (int)(leaf & kLeafFirstMask), count = (int)(leaf >> 28) + 1;
     bool stop = false;
@@ -311,6 +315,7 @@ PT_DEV void trav_leaf_step(Trav& t, const SceneRec& sc, const int* lds_stack, co
 #if PT_LEAF_SINGLE
     else if (count > 1) t.cur = ~(int)(((uint32_t)(first + 1) & kLeafFirstMask) | ((uint32_t)(count - 2) << 28));
 #endif
+    else if (keep_next) t.cur = keep;
     else trav_pop(t, sc, lds_stack, spill);
 }
 

@@ -298,18 +298,48 @@ PT_DEV void trace_persistent(const SceneRec& sc, const WfBuffers& wf, int* my_st
 #define PT_NODE_MIN 16        // (swept 4..32 at 8 samples per launch: 16) leave the node phase early when fewer lanes than this hold an inner node AND some lane waits at a leaf
                               // (swept 1/4/8/12/16/32 on MI355X: 2195/2326/2359/2360/2356/2294 Mrays/s)
 #endif
+#ifndef PT_POSTPONE_LEAF
+#define PT_POSTPONE_LEAF 0    // 1: a lane that reaches a leaf while others still step nodes sets the leaf aside and goes on with its next stack entry.
+                              // MEASURED (round 3, bit-identical images): lanes stepping per node iteration 42.6 -> 44.5 of 64, but 25 % more node
+                              // visits (12.6 -> 15.8 per ray; occlusion rays +36 %: the postponed leaf is usually the hit that ends them) --
+                              // traversal 13.9 -> 16.1 ms per 8-spp launch.  Off; kept as a build option for the record.
+#endif
         for (;;) {
+#if PT_POSTPONE_LEAF
+            // Speculative traversal (Aila & Laine): a third of the lanes of a node iteration used to sit at a leaf, waiting for the wave's leaf
+            // phase (tools/util_probe.py: 42.6 of 59 lanes stepping).  Such a lane now POSTPONES its leaf -- one at a time, and only if its
+            // stack holds something to go on with -- and keeps stepping; the leaf phase tests the postponed leaf FIRST, so triangles are
+            // tested in the order they were reached and every ray finds the hit it found before.  The node steps taken meanwhile used the
+            // older, longer interval: a superset of the nodes, never a different hit.
+            if (has && t.cur < 0 && t.cur != kTravDone && t.post == kTravDone && t.sp > 0) { t.post = t.cur; trav_pop(t, sc, my_stack, spill); }
+#endif
             const unsigned long long at_node = __ballot(has && t.cur >= 0);
             if (at_node == 0) break;
-            if (PT_NODE_MIN > 1 && (int)__popcll(at_node) < PT_NODE_MIN && __ballot(has && t.cur < 0 && t.cur != kTravDone) != 0) break;
+            if (PT_NODE_MIN > 1 && (int)__popcll(at_node) < PT_NODE_MIN && __ballot(has && t.cur < 0 && (t.cur != kTravDone || t.post != kTravDone)) != 0) break;
             PT_UTIL(0, 1); PT_UTIL(1, __popcll(at_node)); PT_UTIL(6, __popcll(__ballot(has)));
             if (has && t.cur >= 0) trav_node_step<COUNT, MODE == 0>(t, sc, my_stack, spill, st);
         }
         // ---- leaf phase
 #ifdef PT_UTIL_PROBE
-        { const unsigned long long at_leaf = __ballot(has && t.cur != kTravDone && t.cur < 0); if (at_leaf) { PT_UTIL(2, 1); PT_UTIL(3, __popcll(at_leaf)); } }
+        { const unsigned long long at_leaf = __ballot(has && ((t.cur != kTravDone && t.cur < 0) || t.post != kTravDone)); if (at_leaf) { PT_UTIL(2, 1); PT_UTIL(3, __popcll(at_leaf)); } }
 #endif
+#if PT_POSTPONE_LEAF
+        // the postponed leaf first (the lane then goes on with the entry it had moved on to, unless the ray ended there), then the leaf the
+        // lane stands at: ONE copy of the leaf code, run at most twice
+#pragma nounroll
+        for (int pass = 0; pass < 2; pass++) {
+            const bool first_pass = pass == 0;
+            const bool mine = has && (first_pass ? t.post != kTravDone : (t.cur != kTravDone && t.cur < 0));
+            if (!__any(mine)) continue;
+            if (mine) {
+                const int keep = t.cur;
+                if (first_pass) { t.cur = t.post; t.post = kTravDone; }
+                trav_leaf_step<COUNT>(t, sc, my_stack, spill, st, first_pass, keep);
+            }
+        }
+#else
         if (has && t.cur != kTravDone && t.cur < 0) trav_leaf_step<COUNT>(t, sc, my_stack, spill, st);
+#endif
         // ---- retire finished rays
         if (has && t.cur == kTravDone) {
             if (MODE == 0) {
