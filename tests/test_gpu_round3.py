@@ -479,3 +479,40 @@ def test_a_thousand_instances_sharing_one_mesh_match_the_oracle(R, oracle_lib):
     with pytest.raises(MiptError):
         r.set_instances(inst + [inst[0]])                              # 1001 rows: PT_ERR_CAPACITY (upstream logs and skips, :294-297)
     r.close(); fresh.close(); o.close()
+
+
+def test_clustering_builder_that_gives_up_falls_back_to_the_radix_tree(R, oracle_lib):
+    """PLOC only guarantees one merge per round, so a long MONOTONE chain -- collinear, degenerate (zero-area) boxes with growing
+    gaps, where cluster i prefers i - 1 and i - 1 prefers i - 2 -- needs O(n) rounds and ran into the round cap, which failed pt_build_accel
+    outright (hipErrorUnknown) although the radix builder handles the scene.  Every way the clustering can give up now falls back to the radix
+    tree over the same Morton order: the scene renders, like the oracle's, and pt_stats says how it was built."""
+    from gltf_renderer_amd import meshgen
+    f32 = np.float32
+    n = 12000
+    # points on a line with geometrically growing gaps, one degenerate (zero-area, zero-extent-box) triangle each, plus one real triangle
+    x = np.cumsum(1e-4 * 1.0008 ** np.arange(n)).astype(f32)
+    pos = np.zeros((3 * n, 3), f32); pos[:, 0] = np.repeat(x, 3); pos[:, 2] = 5.0
+    tri = np.array([[-1, 0, -1], [1, 0, -1], [0, 0, 1]], f32)
+    pos = np.concatenate([tri, pos])
+    mesh = meshgen.Mesh(pos, np.arange(len(pos)), normals=np.tile(np.array([[0, -1, 0]], f32), (len(pos), 1)), uv0=np.tile(np.array([[0, 1], [1, 1], [0.5, 0]], f32), (n + 1, 1)))
+    s = scenes.single_triangle(64)
+    s.instances.clear(); s.mesh_records.clear(); s.buffers.clear(); s.triangles = 0
+    s.add_mesh(mesh, None, 0)
+    st = copy_settings(s.settings); st.debug_output = abi.DEBUG_OUTPUT_HIT_KIND; st.flags &= ~abi.FLAG_ACCUMULATE; st.use_frame_as_seed = 0; st.seed = 3
+    imgs = {}
+    for b in (abi.BUILDER_LBVH, abi.BUILDER_PLOC, abi.BUILDER_PLOC_REINSERT):
+        r = R(); r.set_accel_builder(b); h = s.upload(r)
+        out = r.create_output(s.width, s.height)
+        r.trace(st, s.execute_params(0), out)                       # must not raise
+        imgs[b] = r.readback(out)
+        q = r.stats()
+        print("monotone strip of %d degenerate triangles, builder %d: fallbacks %d, stack need %d / capacity %d" % (n, b, q.accel_builder_fallbacks, q.bvh_stack_need, q.bvh_stack_capacity))
+        assert q.bvh_triangles == n + 1 and q.bvh_stack_capacity >= q.bvh_stack_need
+        r.close()
+    o = oracle_lib.Oracle(); ho = s.upload(o)
+    b = np.zeros((s.height, s.width, 4), np.float32)
+    o.trace(st, s.execute_params(0), b)
+    for k, img in imgs.items():
+        assert np.array_equal(img, b), k
+    assert (b[..., 0] == 1).mean() > 0.05                          # the real triangle is in view
+    o.close()
