@@ -90,6 +90,8 @@ struct pt_ctx {
     void* d_tonemap = nullptr; size_t tonemap_cap = 0;         // pt_tonemap's device scratch (float RGB + RGBA8), reused
     pt::ExchangeState* exchange = nullptr;                         // pt_exchange_* (exchange.hip)
     int32_t* d_deep = nullptr; size_t deep_cap = 0;                // deep traversal stack (SceneRec::deep_stack), only for trees that need > 64 entries
+    uint32_t* d_occ = nullptr; size_t occ_pixels = 0; uint32_t occ_w = 0, occ_h = 0; bool occ_stale = true;   // occluder cache (pt_wavefront.hip), per output resolution
+    bool occ_enabled = false;                                       // only with a -DPT_OCC_CACHE=1 build and MIPT_OCC_CACHE=1: measured, no gain (pt_wavefront.hip)
     bool stage_timing = false;                                 // pt_enable_stage_timing
     StageTimers timers;
     int kernel_mode = PT_MODE_WAVEFRONT;
@@ -291,6 +293,7 @@ public:
                 return ctx->fail(PT_ERR_DEVICE, std::string("acceleration-structure build: ") + (ctx->scratch.why.empty() ? hipGetErrorString(be) : ctx->scratch.why.c_str()));
             }
             ctx->accel_builds++;
+            ctx->occ_stale = true;                 // triangle indices changed: the occluder cache's hints point at other triangles now
         }
         HIPOK(hipEventRecord(ctx->ev_accel[1], ctx->stream));
         ctx->have_accel = true;
@@ -433,8 +436,22 @@ public:
                     HIPOK(hipMalloc(&ctx->d_workspace, need));
                     ctx->workspace_cap = need;
                 }
+                // the occluder cache follows the output resolution; triangle indices change with every full build (not with a refit), which
+                // makes its content stale: hints are re-validated by an exact test anyway, but a clean table costs one memset
+                uint32_t* occ = nullptr;
+                if (ctx->occ_enabled && settings->debug_output == PT_DEBUG_OUTPUT_NONE) {
+                    const size_t px = (size_t)ep->width * ep->height;
+                    if (px != ctx->occ_pixels || ep->width != ctx->occ_w) {
+                        HIPOK(hipStreamSynchronize(ctx->stream));
+                        hipFree(ctx->d_occ); ctx->d_occ = nullptr; ctx->occ_pixels = 0;
+                        if (hipMalloc((void**)&ctx->d_occ, px * 8 * 4) == hipSuccess) { ctx->occ_pixels = px; ctx->occ_w = ep->width; ctx->occ_h = ep->height; ctx->occ_stale = true; }
+                        else (void)hipGetLastError();
+                    }
+                    if (ctx->d_occ && ctx->occ_stale) { HIPOK(hipMemsetAsync(ctx->d_occ, 0xff, ctx->occ_pixels * 8 * 4, ctx->stream)); ctx->occ_stale = false; }
+                    occ = ctx->d_occ;
+                }
                 HIPOK(launch_wavefront(sc, fc, (float4*)ep->output, ctx->d_counters, ctx->counters_enabled, ctx->d_workspace, stage_blocks,
-                                       ctx->stage_timing ? &ctx->timers : nullptr, ctx->stream));
+                                       ctx->stage_timing ? &ctx->timers : nullptr, ctx->stream, occ));
             }
             HIPOK(hipGetLastError());
             HIPOK(hipEventRecord(ctx->ev_trace[1], ctx->stream));
@@ -575,6 +592,7 @@ int pt_create(int device, void* hip_stream, const float* sheen_e_16x16, pt_ctx**
         else if (!strcmp(b, "lbvh")) ctx->scratch.builder = PT_BUILDER_LBVH;
         else if (!strcmp(b, "reinsert")) ctx->scratch.builder = PT_BUILDER_PLOC_REINSERT;
     }
+    if (const char* b = getenv("MIPT_OCC_CACHE")) ctx->occ_enabled = atoi(b) != 0;     // 0: no occluder cache (A/B runs; images are identical either way)
     if (const char* b = getenv("MIPT_REINSERT_PASSES")) {    // tuning aid (tools/builder_probe.py): passes of PT_BUILDER_PLOC_REINSERT
         const int v = atoi(b);
         if (v >= 0 && v <= 64) ctx->scratch.reinsert_passes = v;
@@ -604,6 +622,7 @@ void pt_destroy(pt_ctx* ctx) {
     hipFree(ctx->d_touched);
     exchange_free(ctx->exchange);
     hipFree(ctx->d_deep);
+    hipFree(ctx->d_occ);
     for (int k = 0; k < StagingRing::kSlots; k++) {
         if (ctx->staging.host[k]) hipHostFree(ctx->staging.host[k]);
         if (ctx->staging.done[k]) hipEventDestroy(ctx->staging.done[k]);

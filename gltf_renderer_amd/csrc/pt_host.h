@@ -106,8 +106,9 @@ struct StageTimers {
 };
 void launch_megakernel(const SceneRec& sc, const FrameConstants& fc, float4* output, Counters* counters, bool count, hipStream_t stream);
 size_t wavefront_workspace_bytes(const FrameConstants& fc, int stage_blocks);
+// occ_cache: the context's occluder cache (res_x * res_y * 8 words, persistent across calls; nullptr = none), see WfBuffers::occ_cache
 hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4* output, Counters* counters, bool count, void* workspace,
-                            int stage_blocks, StageTimers* timers, hipStream_t stream);
+                            int stage_blocks, StageTimers* timers, hipStream_t stream, uint32_t* occ_cache);
 
 // ---- exchange.hip: the per-frame tile exchange of the sharded renderer (RCCL bound at run time) ---------------------------
 struct ExchangeState;

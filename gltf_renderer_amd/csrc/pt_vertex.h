@@ -26,6 +26,8 @@ struct Followups {
     float b_pdf;
     bool b_mis;
     unsigned counted_shadow;   // shadow rays the reference traces but whose result a debug mode discards
+    uint32_t light_index;      // the punctual light the light-NEE sample picked (occluder cache key)
+    uint32_t hint_env, hint_light;   // occluder-cache words of the two shadow rays (fetched here, early, so that the push does not wait for them)
 };
 
 PT_DEV vec3 shade_miss(const SceneRec& sc, const FrameConstants& fc, vec3 dir, const PathState& ps) {
@@ -57,9 +59,11 @@ extern __device__ unsigned long long pt_timing[12];
 // the in-place code, its LDS tables and its registers are not compiled in); otherwise it is drawn here.
 template <bool PRE = false>
 PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint32_t seed, uint32_t px, uint32_t py, const Ray& ray, const HitRec& hit,
-                              const RawPacket& packet_in, const ShadePacket* packet_at, PathState& ps, Followups& fu, unsigned& taps, const EnvSample* pre = nullptr) {
+                              const RawPacket& packet_in, const ShadePacket* packet_at, PathState& ps, Followups& fu, unsigned& taps, const EnvSample* pre = nullptr,
+                              const uint32_t* occ_row = nullptr) {
     const uint32_t flags = fc.flags;
-    fu.add = v3(0); fu.overwrite = false; fu.counted_shadow = 0;
+    fu.add = v3(0); fu.overwrite = false; fu.counted_shadow = 0; fu.light_index = 0; fu.hint_env = fu.hint_light = 0xffffffffu;
+    if (occ_row) fu.hint_env = occ_row[0];
     fu.q_env = fu.q_light = fu.q_bounce = false;
 #ifdef PT_TIMING
     unsigned long long _sec[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, _t = __builtin_readcyclecounter();
@@ -158,6 +162,8 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
         float u = next_random(px, py, seed, ps.rc).x;
         uint32_t li = f2u(u * (float)fc.num_of_lights);
         li = min(li, (uint32_t)(fc.num_of_lights - 1));                                              // u may be exactly 1 (quirk q17)
+        fu.light_index = li;
+        if (occ_row) fu.hint_light = occ_row[1u + li % 7u];
         float pdf = fdiv(1.0f, (float)fc.num_of_lights);
         vec3 ldir, lcol;
         bool cone_terms_staged;

@@ -46,6 +46,13 @@ namespace pt {
 
 constexpr uint32_t kShards = 256;
 constexpr uint32_t kMissTri = 0x7fffffffu;
+constexpr uint32_t kNoHint = 0xffffffffu;
+#ifndef PT_OCC_CACHE
+#define PT_OCC_CACHE 0        // 1: occluder cache for the shadow rays of first path vertices (WfBuffers::occ_cache).  MEASURED (round 3, images
+                              // bit-identical): node visits per ray 12.6 -> 10.9, traversal 13.85 -> 13.6 ms, shade +1.5 % (the hint fetches):
+                              // no gain -- the rays it shortens are the coherent, cheap ones, and a wave still lasts as long as its longest ray.
+                              // Off; kept as a build option for the record (profiles/EXPERIMENTS.md).
+#endif
 constexpr uint32_t kCounterStride = 16;      // one 64-B line per shard counter
 constexpr int kCounterArrays = 7;
 
@@ -66,7 +73,13 @@ struct WfBuffers {
     float4* env_b;        // traces the entry (env_prepass): (direction, pdf), (radiance, -)
     // shadow queue, kShards segments of 2 * seg_cap entries: (o.xyz, bits: slot | is_light << 31), (d.xyz, tmax)
     float4* sh_o;
-    float4* sh_d;
+    float4* sh_d;         // (d.xyz, bits: occluder hint -- a triangle index, kNoHint for none; the rays' tmax is the constant max_ray_length)
+    uint32_t* sh_c;       // per shadow entry: where the ray's occluder goes in occ_cache (kNoHint: nowhere)
+    // Occluder cache (PT_OCC_CACHE): per pixel, eight triangle indices -- [0] the last triangle that occluded an environment shadow ray of the
+    // pixel's FIRST path vertex, [1 + light % 7] the same for that punctual light.  A hint, never a result: the shadow ray tests the hinted
+    // triangle first, with the same intersection routine and flags; if it hits, the ray is occluded exactly as the traversal would have found,
+    // by whichever triangle.  Persists across pt_trace calls (the next samples of a pixel meet the occluders of the last ones).
+    uint32_t* occ_cache;
     uint32_t* cnt[7];     // per shard (stride kCounterStride): entry counts of closest queue 0, closest queue 1, shadow queue (even bounces);
                           // [3], [4]: dynamic-fetch heads of the closest / shadow trace stages; [5]: shadow-queue count of odd bounces
                           // (the shadow count ping-pongs so that the fused traversal stage can zero the one the NEXT shade stage fills
@@ -242,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_generate(FrameConstants fc, WfBuf
 PT_DEV int shadow_counter(int bounce) { return (bounce & 1) ? 5 : 2; }
 template <bool COUNT, int MODE>
 PT_DEV void trace_persistent(const SceneRec& sc, const WfBuffers& wf, int* my_stack, const ShardView& sv, int cur, uint32_t rf_closest, uint32_t rmask,
-                             uint32_t flags, LaneStats& st) {
+                             uint32_t flags, LaneStats& st, float shadow_tmax = 0.0f, bool use_occ_cache = false) {
     // MODE 0: `cur` = closest queue (0 / 1).  MODE 1: `cur` = index of the shadow-queue counter (shadow_counter(bounce)).
     const uint32_t n = wf.cnt[cur][sv.shard * kCounterStride];
     uint32_t* head = wf.cnt[MODE == 0 ? 3 : 4] + sv.shard * kCounterStride;
@@ -252,7 +265,7 @@ PT_DEV void trace_persistent(const SceneRec& sc, const WfBuffers& wf, int* my_st
     Trav t;
     t.cur = kTravDone; t.sp = 0;
     bool has = false, exhausted = (n == 0);
-    uint32_t entry = 0, slot_bits = 0;
+    uint32_t entry = 0, slot_bits = 0, occ_at = kNoHint;
 #ifdef PT_UTIL_PROBE
     unsigned long long u_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // wave-level: [0] node iterations [1] lanes stepping [2] leaf iterations [3] lanes testing [4] refills [5] lanes refilled [6] lanes holding a ray, summed over node iterations
 #endif
@@ -277,11 +290,21 @@ PT_DEV void trace_persistent(const SceneRec& sc, const WfBuffers& wf, int* my_st
                     } else {
                         const float4 o = QLD(wf.sh_o[base + i]), d = QLD(wf.sh_d[base + i]);
                         slot_bits = __float_as_uint(o.w);
-                        ray.o = v3(o.x, o.y, o.z); ray.tmin = 0; ray.d = v3(d.x, d.y, d.z); ray.tmax = d.w;
+                        ray.o = v3(o.x, o.y, o.z); ray.tmin = 0; ray.d = v3(d.x, d.y, d.z); ray.tmax = shadow_tmax;
                         const bool alpha_shadow = (slot_bits >> 31) && (flags & PT_FLAG_ALPHA_SHADOWS);          // TraceShadowRay :724-742
                         uint32_t srf = (flags & PT_FLAG_CULL_BACKFACE) ? RF_CULL_BACK : 0;
                         srf |= alpha_shadow ? RF_FORCE_NON_OPAQUE : RF_ACCEPT_FIRST;
                         trav_init(t, sc, ray, srf, 0xff, 1, alpha_shadow ? 1.0f : 0.0f);
+#if PT_OCC_CACHE
+                        // occluder cache: an accept-first ray whose pixel remembers an occluder tests that triangle FIRST -- as a one-triangle leaf,
+                        // with the root waiting on the stack -- and ends there if it still occludes
+                        occ_at = kNoHint;
+                        if (use_occ_cache) {
+                            const uint32_t hint = __float_as_uint(d.w);
+                            occ_at = alpha_shadow ? kNoHint : QLD(wf.sh_c[base + i]);
+                            if (occ_at != kNoHint && hint < sc.num_tris && hint < kLeafFirstMask && t.cur >= 0) { my_stack[0] = t.cur; t.sp = 1; t.cur = ~(int)hint; }
+                        }
+#endif
                     }
                     entry = i;
                     has = true;
@@ -348,6 +371,9 @@ PT_DEV void trace_persistent(const SceneRec& sc, const WfBuffers& wf, int* my_st
             } else {
                 const float tr = t.committed ? t.transmission : 1.0f;                                              // ShadowMiss :1081-1085
                 const uint32_t slot = slot_bits & 0x7fffffffu;
+#if PT_OCC_CACHE
+                if (use_occ_cache && occ_at != kNoHint && t.committed) wf.occ_cache[occ_at] = (uint32_t)t.best.tri;   // remember the occluder
+#endif
                 float* w = (slot_bits >> 31) ? &PEND_LIGHT(slot).w : &PEND_ENV(slot).w;
                 *w = tr;
             }
@@ -440,7 +466,7 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_traverse(SceneRec
     if (env_prepass_wanted(sc, fc, bounce + 1)) env_prepass(sc, fc, wf, s_stack, sv, nxt, false);
     if (sv.member == 0 && threadIdx.x == 0) { wf.cnt[nxt ^ 1][sv.shard * kCounterStride] = 0; wf.cnt[shadow_counter(bounce + 1)][sv.shard * kCounterStride] = 0; wf.cnt[6][sv.shard * kCounterStride] = 0; }
     LaneStats st_shadow = {0, 0, 0, 0}, st = {0, 0, 0, 0};
-    trace_persistent<COUNT, 1>(sc, wf, s_stack + threadIdx.x, sv, shadow_counter(bounce), 0, 0xff, flags, st_shadow);
+    trace_persistent<COUNT, 1>(sc, wf, s_stack + threadIdx.x, sv, shadow_counter(bounce), 0, 0xff, flags, st_shadow, fc.max_ray_length, wf.occ_cache != nullptr && bounce == 0);
     trace_persistent<COUNT, 0>(sc, wf, s_stack + threadIdx.x, sv, nxt, rf, rmask, 0, st);
     if (COUNT) {
         flush_counters(counters, threadIdx.x & 63, 0, 0, 0, 0, st_shadow, true); flush_counters(counters, threadIdx.x & 63, 0, 0, 0, 0, st);
@@ -511,6 +537,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
         const bool active = i < n;
 #endif
         bool push_env = false, push_light = false, push_bounce = false;
+        uint32_t occ_pixel = kNoHint;                       // first-vertex hits: the pixel's row of the occluder cache
         Followups fu;
         fu.q_env = fu.q_light = fu.q_bounce = false;
         uint32_t slot = 0;
@@ -564,10 +591,16 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
                 uint32_t px, py;
                 slot_pixel(fc, slot, px, py);
                 n_hits++;
-#if PT_ENV_PREPASS
-                const bool done = shade_closest_hit<true>(sc, fc, sample_seed(fc, slot_sample(fc, slot)), px, py, ray, hit, packet, packet_at, ps, fu, st.taps, &es);
+#if PT_OCC_CACHE
+                if (bounce == 0 && wf.occ_cache) occ_pixel = (py * fc.res_x + px) * 8u;
+                const uint32_t* occ_row = occ_pixel != kNoHint ? wf.occ_cache + occ_pixel : nullptr;
 #else
-                const bool done = shade_closest_hit(sc, fc, sample_seed(fc, slot_sample(fc, slot)), px, py, ray, hit, packet, packet_at, ps, fu, st.taps);
+                const uint32_t* occ_row = nullptr;
+#endif
+#if PT_ENV_PREPASS
+                const bool done = shade_closest_hit<true>(sc, fc, sample_seed(fc, slot_sample(fc, slot)), px, py, ray, hit, packet, packet_at, ps, fu, st.taps, &es, occ_row);
+#else
+                const bool done = shade_closest_hit(sc, fc, sample_seed(fc, slot_sample(fc, slot)), px, py, ray, hit, packet, packet_at, ps, fu, st.taps, nullptr, occ_row);
 #endif
                 if (fu.overwrite) L = v3(0);
                 L += fu.add;
@@ -585,16 +618,31 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
 #endif
         }
         // ---- compaction into this shard's shadow segment and next closest-ray segment (wave-uniform control flow)
+        // occluder hints of a first-vertex hit's two shadow rays: both cache words of the pixel fetched together (a wave's pixels are an 8x8 block:
+        // eight 256-B runs), only by the stage that shades first vertices
+        uint32_t at_env = kNoHint, at_light = kNoHint, hint_env = kNoHint, hint_light = kNoHint;
+#if PT_OCC_CACHE
+        if (bounce == 0 && occ_pixel != kNoHint) {         // (the two cache words were fetched inside shade_closest_hit, well before this point)
+            at_env = occ_pixel; at_light = occ_pixel + 1u + fu.light_index % 7u;
+            hint_env = fu.hint_env; hint_light = fu.hint_light;
+        }
+#endif
         const uint32_t ie = queue_push(cnt_shadow, push_env);
         if (push_env) {
             QST(wf.sh_o[sbase + ie], make_float4(fu.origin_above.x, fu.origin_above.y, fu.origin_above.z, __uint_as_float(slot)));
-            QST(wf.sh_d[sbase + ie], make_float4(fu.env_dir.x, fu.env_dir.y, fu.env_dir.z, fc.max_ray_length));
+            QST(wf.sh_d[sbase + ie], make_float4(fu.env_dir.x, fu.env_dir.y, fu.env_dir.z, __uint_as_float(hint_env)));
+#if PT_OCC_CACHE
+            if (bounce == 0 && wf.occ_cache) QST(wf.sh_c[sbase + ie], at_env);
+#endif
             n_shadow++;
         }
         const uint32_t il = queue_push(cnt_shadow, push_light);
         if (push_light) {
             QST(wf.sh_o[sbase + il], make_float4(fu.origin_above.x, fu.origin_above.y, fu.origin_above.z, __uint_as_float(slot | 0x80000000u)));
-            QST(wf.sh_d[sbase + il], make_float4(fu.light_dir.x, fu.light_dir.y, fu.light_dir.z, fc.max_ray_length));
+            QST(wf.sh_d[sbase + il], make_float4(fu.light_dir.x, fu.light_dir.y, fu.light_dir.z, __uint_as_float(hint_light)));
+#if PT_OCC_CACHE
+            if (bounce == 0 && wf.occ_cache) QST(wf.sh_c[sbase + il], at_light);
+#endif
             n_shadow++;
         }
         const uint32_t ib = queue_push(cnt_next, push_bounce);
@@ -620,12 +668,12 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
 
 // occlusion traversal of the shadow queue (TraceShadowRay :724-742); writes the transmission next to its pending term.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_shadow(SceneRec sc, WfBuffers wf, int bounce, uint32_t flags, Counters* __restrict__ counters) {
+__global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_shadow(SceneRec sc, WfBuffers wf, int bounce, uint32_t flags, float tmax, Counters* __restrict__ counters) {
     __shared__ int s_stack[kStackLds * kBlock];
     stage_luts(sc);
     const ShardView sv = shard_view(wf);
     LaneStats st = {0, 0, 0, 0};
-    trace_persistent<COUNT, 1>(sc, wf, s_stack + threadIdx.x, sv, shadow_counter(bounce), 0, 0xff, flags, st);
+    trace_persistent<COUNT, 1>(sc, wf, s_stack + threadIdx.x, sv, shadow_counter(bounce), 0, 0xff, flags, st, tmax, wf.occ_cache != nullptr && bounce == 0);
     if (COUNT) { flush_counters(counters, threadIdx.x & 63, 0, 0, 0, 0, st, true); if (st.deep) atomicAdd(&counters->deep_pushes, (unsigned long long)st.deep); }
     else if (st.overflow | st.deep) flush_rare(counters, st);
 }
@@ -682,7 +730,7 @@ size_t wavefront_workspace_bytes(const FrameConstants& fc, int stage_blocks) {
     const uint32_t bps = blocks_per_shard_for(stage_blocks);
     const size_t slots = state_slots_for((size_t)fc.my_tiles * kBlock * fc.spp);
     const size_t q = (size_t)kShards * seg_cap_for(fc, bps);
-    return slots * (5 * 16) + q * (4 * 16 + 4 * 16 + 16 + 2 * 16 + 2 * 2 * 16) + kCounterArrays * kShards * kCounterStride * 4 + 48 * 256;
+    return slots * (5 * 16) + q * (4 * 16 + 4 * 16 + 16 + 2 * 16 + 2 * 2 * 16 + 2 * 4) + kCounterArrays * kShards * kCounterStride * 4 + 52 * 256;
 }
 
 static WfBuffers carve(void* base, const FrameConstants& fc, int stage_blocks) {
@@ -709,6 +757,8 @@ static WfBuffers carve(void* base, const FrameConstants& fc, int stage_blocks) {
     wf.env_b = (float4*)take(q * 16);
     wf.sh_o = (float4*)take(q * 2 * 16);
     wf.sh_d = (float4*)take(q * 2 * 16);
+    wf.sh_c = (uint32_t*)take(q * 2 * 4);
+    wf.occ_cache = nullptr;
     wf.capacity = slots;
     return wf;
 }
@@ -717,7 +767,7 @@ int traversal_stack_capacity() { return kStackLds + kStackSpill; }
 size_t traversal_grid_lanes(int stage_blocks) { return (size_t)kShards * blocks_per_shard_for(stage_blocks) * kBlock; }
 
 hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4* output, Counters* counters, bool count, void* workspace,
-                            int stage_blocks, StageTimers* timers, hipStream_t stream) {
+                            int stage_blocks, StageTimers* timers, hipStream_t stream, uint32_t* occ_cache) {
     if (timers) timers->used = 0;
     if (fc.my_tiles == 0) return hipSuccess;
     // pt_enable_stage_timing: an event after every launch, so that the time of a launch can be split by stage (diagnostic: the
@@ -738,6 +788,7 @@ hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4
     };
     const uint32_t slots = fc.my_tiles * kBlock * fc.spp;
     WfBuffers wf = carve(workspace, fc, stage_blocks);
+    wf.occ_cache = PT_OCC_CACHE ? occ_cache : nullptr;
     hipError_t e = hipMemsetAsync(wf.cnt[0], 0, (size_t)kCounterArrays * kShards * kCounterStride * 4, stream);     // the counter arrays are contiguous
     if (e) return e;
     const dim3 block(kBlock), full(fc.my_tiles), stage(kShards * wf.blocks_per_shard);
@@ -813,8 +864,8 @@ hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4
             if (count) hipLaunchKernelGGL(k_wf_traverse<true>, gt, block, 0, stream, sc, fc, wt, cur ^ 1, b, rf, rmask, flags, counters);
             else hipLaunchKernelGGL(k_wf_traverse<false>, gt, block, 0, stream, sc, fc, wt, cur ^ 1, b, rf, rmask, flags, counters);
         } else {                                                                                      // the last vertex pushes no bounce ray
-            if (count) hipLaunchKernelGGL(k_wf_shadow<true>, gt, block, 0, stream, sc, wt, b, flags, counters);
-            else hipLaunchKernelGGL(k_wf_shadow<false>, gt, block, 0, stream, sc, wt, b, flags, counters);
+            if (count) hipLaunchKernelGGL(k_wf_shadow<true>, gt, block, 0, stream, sc, wt, b, flags, fc.max_ray_length, counters);
+            else hipLaunchKernelGGL(k_wf_shadow<false>, gt, block, 0, stream, sc, wt, b, flags, fc.max_ray_length, counters);
         }
         mark(STAGE_SHADOW);
     }
@@ -828,8 +879,8 @@ hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4
         mark(STAGE_TRACE);
         hipLaunchKernelGGL(k_wf_shade, stage, block, 0, stream, sc, fc, wf, cur, b, counters);
         mark(STAGE_SHADE);
-        if (count) hipLaunchKernelGGL(k_wf_shadow<true>, stage, block, 0, stream, sc, wf, b, flags, counters);
-        else hipLaunchKernelGGL(k_wf_shadow<false>, stage, block, 0, stream, sc, wf, b, flags, counters);
+        if (count) hipLaunchKernelGGL(k_wf_shadow<true>, stage, block, 0, stream, sc, wf, b, flags, fc.max_ray_length, counters);
+        else hipLaunchKernelGGL(k_wf_shadow<false>, stage, block, 0, stream, sc, wf, b, flags, fc.max_ray_length, counters);
         mark(STAGE_SHADOW);
     }
 #endif
