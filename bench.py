@@ -14,9 +14,10 @@ through the thin late bounces.  The reference-semantics figure -- one 1-spp `pt_
 N > 1: the frame is sharded by 16x16 pixel tile (tile t -> rank t % N), every rank renders its tiles into ITS OWN accumulation
 image, and ONE exchange per step assembles the frame on rank 0 -- `pt_exchange_frame` inside libmipt.so (RCCL on the launch
 stream: every rank sends its own tiles point to point over its direct xGMI link, or `--exchange reduce`: ncclReduce of a
-zero-masked copy).  The headline line is STRONG scaling: the same 8-spp step split N ways (total work fixed, the BASELINE metric
-on N GPUs).  The same run then times the WEAK variant (8 x N samples per step: per-GPU work fixed) and reports it in
-`weak_scaling`.  `python bench.py --gpus N` started plainly (no WORLD_SIZE) launches its own N ranks with torch.distributed.run as a
+zero-masked copy).  The headline line is WEAK scaling, as the partitioned path calls for: every rank keeps the per-GPU work of the N = 1
+step -- its 1/N of the tiles carries 8 x N samples per step (the frame is the same 1920x1080; N GPUs deliver N times the samples per
+unit time), `"scaling": "weak"`.  The same run then times the STRONG variant (the 8-spp step split N ways: total work fixed, each rank
+left with the work of one 1-spp frame) and reports it in `strong_scaling`; `--headline strong` swaps the two.  `python bench.py --gpus N` started plainly (no WORLD_SIZE) launches its own N ranks with torch.distributed.run as a
 child process before anything touches a GPU, and exits non-zero if the node has fewer than N devices; the line's `n_gpus` is always the
 number of ranks that rendered.  If RCCL cannot be brought up inside libmipt.so on every rank the run FAILS (no fallback transport).
 `--backend gloo --single-device` rehearses the rank logic on one GPU through the torch.distributed test double
@@ -89,7 +90,8 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="rehearsal only: every rank uses cuda:0 (RCCL needs one device per rank)")
     ap.add_argument("--spp", type=int, default=0, help="samples per pixel per step (sample batch); default 8")
     ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"], help="per-step assembly on rank 0: own-tile gather (default) or reduce of the zero-masked copy")
-    ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the second (weak-scaling) timed loop")
+    ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the second timed loop (the scaling mode that is not the headline)")
+    ap.add_argument("--headline", default="weak", choices=["weak", "strong"], help="N > 1: which scaling mode the headline line reports (the other one rides in the same line)")
     ap.add_argument("--cull-null-shadow", action="store_true", help="experiment: pt_set_null_shadow_culling(1) -- same image, fewer shadow rays than the reference traces (off for the headline line)")
     ap.add_argument("--animate", action="store_true", help="dynamic path (--config figure / sponza_figure): skin -> BVH refit -> trace every step, accumulation reset each frame")
     ap.add_argument("--rebuild", action="store_true", help="with --animate: full LBVH rebuild every frame instead of the refit (the round-1 behaviour, for comparison)")
@@ -278,9 +280,12 @@ def main():
             dist.all_reduce(ry, op=dist.ReduceOp.SUM)
         return float(el.item()), float(ry.item()), [a.elapsed_time(b) for a, b in ev]
 
-    # ---- headline: the 8-spp step (split N ways when sharded: strong scaling)
-    elapsed, rays_total, kernel_ms = timed_run(base_spp, 0)
-    spp = base_spp
+    # ---- headline.  N = 1: the 8-spp step.  N > 1, weak scaling (default): per-GPU work as at N = 1 -- each rank's 1/N of the tiles carries
+    # 8 x N samples per step; strong scaling (--headline strong): the 8-spp step split N ways
+    weak_spp = min(base_spp * world, 64)              # (PT_MAX_SAMPLES_PER_TRACE = 64: N = 8 at 8 spp is exactly the limit)
+    headline_weak = world > 1 and args.headline == "weak" and not args.animate
+    spp = weak_spp if headline_weak else base_spp
+    elapsed, rays_total, kernel_ms = timed_run(spp, 0)
 
     result = None
     if rank == 0:
@@ -302,17 +307,21 @@ def main():
                        "bvh_stack_need": int(st_build.bvh_stack_need), "scene_setup_s": round(t_setup, 1)},
         }
         if world > 1:
-            result["scaling"] = "strong"          # N = 1 has no scaling mode: the key is omitted there
+            result["scaling"] = "weak" if headline_weak else "strong"          # N = 1 has no scaling mode: the key is omitted there
+            result["config"]["scaling_note"] = ("weak: per-GPU work fixed -- every rank renders its 1/%d of the tiles with %d samples per step (8 per GPU); "
+                                                "strong_scaling = the 8-spp step split %d ways" % (world, spp, world)) if headline_weak else \
+                                               ("strong: the %d-spp step split %d ways; weak_scaling = %d samples per step" % (spp, world, weak_spp))
             if args.backend != "nccl":
                 result["config"]["parallelism"] += " [REHEARSAL over gloo on %s: not an RCCL measurement]" % ("one GPU" if args.single_device else "the host")
 
-    # ---- N > 1: the weak-scaling variant of the same run (8 x N samples per step, per-GPU work fixed)
+    # ---- N > 1: the other scaling mode of the same run
     if world > 1 and not args.no_weak and not args.animate:
-        wspp = min(base_spp * world, 64)
-        w_elapsed, w_rays, _ = timed_run(wspp, 1000)
+        ospp = base_spp if headline_weak else weak_spp
+        other = "strong" if headline_weak else "weak"
+        w_elapsed, w_rays, _ = timed_run(ospp, 1000)
         if rank == 0:
-            result["weak_scaling"] = {"scaling": "weak", "value": round(w_rays / w_elapsed / 1e6, 3), "unit": "Mrays/s", "samples_per_step": wspp,
-                                      "ms_per_step": round(w_elapsed / args.steps * 1000.0, 4), "ms_per_1spp_frame": round(w_elapsed / args.steps / wspp * 1000.0, 4)}
+            result[other + "_scaling"] = {"scaling": other, "value": round(w_rays / w_elapsed / 1e6, 3), "unit": "Mrays/s", "samples_per_step": ospp,
+                                          "ms_per_step": round(w_elapsed / args.steps * 1000.0, 4), "ms_per_1spp_frame": round(w_elapsed / args.steps / ospp * 1000.0, 4)}
         r.set_samples_per_trace(spp)
 
     # ---- latency of a single-sample launch (one reference frame): median of >= 20 after 3 warm-ups

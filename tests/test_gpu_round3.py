@@ -303,7 +303,8 @@ def test_bench_launches_its_own_ranks_when_started_plainly(tmp_path):
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     res = json.loads(lines[0])
-    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["value"] > 0
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["value"] > 0          # per-GPU work fixed: 16 samples per step on 2 ranks
+    assert res["config"]["samples_per_step"] == 16
     assert "REHEARSAL" in res["config"]["parallelism"]
 
 
