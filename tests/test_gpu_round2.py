@@ -501,9 +501,12 @@ def test_config3_sponza_class_at_8_bounces_matches_the_oracle(R, oracle_lib):
     bias = float((ta[ok].astype(np.float64) - tb[ok]).sum() / tb[ok].astype(np.float64).sum())
     print("config 3, 8 bounces: tone-mapped rel L2 %.3e at 16 spp, %.3e at 64 spp; without the 1 %% worst pixels %.3e -> %.3e; relative bias %.2e; median |diff| %.2e; "
           "pixels with |diff| > 0.05: %.4f; 1-spp pixel-samples beyond 1e-2: %.4f" % (errs[16], errs[64], bulk[16], bulk[64], bias, float(np.median(d)), float((d > 0.05).mean()), frac))
-    assert errs[64] <= 1e-5 and errs[16] <= 1e-5, errs        # whole image; the north_star bar is 1e-3 (measured 3.4e-7 / 3.3e-7)
-    assert bulk[64] <= 1e-5 and bulk[16] <= 1e-5, bulk        # 99 % of the pixels (measured 2.9e-7)
-    assert abs(bias) < 1e-5 and float(np.median(d)) < 1e-6 and (d > 0.05).sum() == 0
+    # THE CONTRACT is the north_star's 1e-3 on the whole image (measured 3.4e-7 / 3.3e-7: printed above).  Agreement far below it holds only
+    # because the oracle and the kernels define sin / cos, division and contraction alike -- a real DXR driver is free not
+    # to; the 1e-4 lines are a regression guard on that co-definition, not a claim about the reference.
+    assert errs[64] <= 1e-3 and errs[16] <= 1e-3, errs
+    assert errs[64] <= 1e-4 and bulk[64] <= 1e-4 and bulk[16] <= 1e-4, (errs, bulk)
+    assert abs(bias) < 1e-4 and (d > 0.05).sum() == 0
     p.close()
 
 
