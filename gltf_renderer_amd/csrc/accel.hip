@@ -6,7 +6,7 @@
 // it (no per-instance ray transform, no overlapping instance boxes to enter):
 //   1. setup     : (instance, primitive) -> world-space 48-B packet, centroid bounds per block, then one block folds them
 //   2. morton    : 63-bit Morton code of the centroid (21 bits / axis)
-//   3. sort      : rocPRIM radix sort of (code, triangle id)                       [library primitive]
+//   3. sort      : stable radix sort of (code, triangle id), seven 9-bit passes         (sort_scan.hip)
 //   4. hierarchy : Karras 2012 radix tree, one lane per internal node
 //   5. fit       : a min/max segment tree over the sorted triangles' boxes; every radix-tree node covers a contiguous range
 //                  of them, so its box is one O(log count) range query -- no inter-lane hand-over, no fences
@@ -18,7 +18,6 @@
 #include <string>
 #include <algorithm>
 #include <vector>
-#include <rocprim/rocprim.hpp>
 
 #include "pt_math.h"
 #include "pt_types.h"
@@ -914,8 +913,7 @@ static hipError_t ensure(AccelScratch& s, size_t n) {
     if ((e = hipMalloc(&s.kept, (cap + 1) * 4))) return e;
     if ((e = hipMalloc(&s.widx, (cap + 1) * 4))) return e;
     if (!s.bounds && (e = hipMalloc(&s.bounds, 6 * 4))) return e;
-    size_t tb = 0;
-    if ((e = rocprim::radix_sort_pairs(nullptr, tb, s.keys_a, s.keys_b, s.vals_a, s.vals_b, cap, 0, 63, (hipStream_t)0))) return e;
+    const size_t tb = radix_sort_temp_bytes(cap);
     if ((e = hipMalloc(&s.sort_temp, tb))) return e;
     s.sort_temp_bytes = tb;
     if ((e = hipMalloc(&s.collapse_counters, (kCollapseMaxLevels + 16) * 4))) return e;
@@ -938,8 +936,7 @@ static hipError_t ensure(AccelScratch& s, size_t n) {
     if ((e = hipMalloc(&s.reins_top, 2 * cap * 4))) return e;
     if ((e = hipMalloc(&s.reins_lock, 2 * cap * 8))) return e;
     if ((e = hipMalloc(&s.reins_state, 4 * cap))) return e;
-    size_t sb = 0;
-    if ((e = rocprim::exclusive_scan(nullptr, sb, s.ploc_valid, s.ploc_pos, 0u, cap, rocprim::plus<uint32_t>(), (hipStream_t)0))) return e;
+    const size_t sb = exclusive_scan_temp_bytes(cap);
     if ((e = hipMalloc(&s.ploc_scan_temp, sb))) return e;
     s.ploc_scan_bytes = sb;
     s.capacity = cap;
@@ -984,8 +981,7 @@ static hipError_t ploc_build(AccelScratch& s, uint32_t n_tris, TriPacket* d_tris
             hipLaunchKernelGGL(k_ploc_nearest, grid, dim3(256), 0, stream, (const PlocCluster*)c[a], (const uint32_t*)(cnt + 4 + a), s.ploc_nn);
             hipLaunchKernelGGL(k_ploc_merge, grid, dim3(256), 0, stream, c[a], (const uint32_t*)(cnt + 4 + a), (const uint32_t*)s.ploc_nn, s.ploc_valid, s.ploc_left,
                                s.ploc_right, s.ploc_count, cnt, (SegBox*)s.reins_box, n_tris);
-            size_t sb = s.ploc_scan_bytes;
-            if ((e = rocprim::exclusive_scan(s.ploc_scan_temp, sb, s.ploc_valid, s.ploc_pos, 0u, (size_t)bound, rocprim::plus<uint32_t>(), stream))) return e;
+            if ((e = exclusive_scan_u32(s.ploc_scan_temp, s.ploc_valid, s.ploc_pos, (size_t)bound, stream))) return e;
             hipLaunchKernelGGL(k_ploc_compact, grid, dim3(256), 0, stream, (const PlocCluster*)c[a], (const uint32_t*)(cnt + 4 + a), (const uint32_t*)s.ploc_valid,
                                (const uint32_t*)s.ploc_pos, c[a ^ 1], cnt + 4 + (a ^ 1));
         }
@@ -1074,8 +1070,7 @@ hipError_t accel_build(AccelScratch& s, const BufferRec* d_buffers, const Instan
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_morton, dim3(g), dim3(256), 0, stream, s.tris_unsorted, n_tris, s.bounds, s.keys_a, s.vals_a);
-    size_t tb = s.sort_temp_bytes;
-    if ((e = rocprim::radix_sort_pairs(s.sort_temp, tb, s.keys_a, s.keys_b, s.vals_a, s.vals_b, (size_t)n_tris, 0, 63, stream))) return e;
+    if ((e = radix_sort_pairs_u64_u32(s.sort_temp, s.keys_a, s.keys_b, s.vals_a, s.vals_b, (size_t)n_tris, stream))) return e;      // sort_scan.hip: stable, 63 bits
     hipLaunchKernelGGL(k_reorder, dim3(g), dim3(256), 0, stream, s.tris_unsorted, s.vals_b, n_tris, d_tris);
     bool radix = s.builder == 0;
     if (!radix) {

@@ -110,6 +110,12 @@ size_t wavefront_workspace_bytes(const FrameConstants& fc, int stage_blocks);
 hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4* output, Counters* counters, bool count, void* workspace,
                             int stage_blocks, StageTimers* timers, hipStream_t stream, uint32_t* occ_cache);
 
+// ---- sort_scan.hip: the build's two data-parallel primitives, hand-written (stable LSD radix sort of (u64, u32) pairs over 63 key bits; u32 exclusive scan)
+size_t radix_sort_temp_bytes(size_t n);
+hipError_t radix_sort_pairs_u64_u32(void* temp, uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, size_t n, hipStream_t stream);   // keys_in / vals_in are scratch
+size_t exclusive_scan_temp_bytes(size_t n);
+hipError_t exclusive_scan_u32(void* temp, const uint32_t* in, uint32_t* out, size_t n, hipStream_t stream);
+
 // ---- exchange.hip: the per-frame tile exchange of the sharded renderer (RCCL bound at run time) ---------------------------
 struct ExchangeState;
 uint32_t tiles_of_rank(uint32_t w, uint32_t h, uint32_t rank, uint32_t world);

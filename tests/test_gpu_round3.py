@@ -517,3 +517,47 @@ def test_clustering_builder_that_gives_up_falls_back_to_the_radix_tree(R, oracle
         assert np.array_equal(img, b), k
     assert (b[..., 0] == 1).mean() > 0.05                          # the real triangle is in view
     o.close()
+
+
+# ---- the build's own sort and scan (csrc/sort_scan.hip: hand-written since round 3, rocPRIM before) ---------------------------------------------
+@pytest.mark.parametrize("n", [1, 63, 2047, 2048, 2049, 100003, 5000011])
+def test_hand_written_radix_sort_is_numpys_stable_sort(R, n):
+    """Stable LSD radix sort of (u64 key, u32 value) pairs over 63 key bits (seven 9-bit passes), against numpy's stable argsort: tile
+    boundaries, a partial last tile, heavy duplicates (stability decides the order of the values), keys that differ only in their top bits
+    and only in their bottom bits, and the all-equal case."""
+    import ctypes as C
+    from gltf_renderer_amd.renderer import load_library
+    r = R()                                                           # a context makes the device current; the hook itself needs none
+    L = load_library()
+    L.pt_debug_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(n)
+    cases = {"random 63-bit": rng.integers(0, 1 << 63, n, dtype=np.uint64),
+             "few distinct (stability)": rng.integers(0, 7, n, dtype=np.uint64) << np.uint64(40),
+             "top bits only": rng.integers(0, 512, n, dtype=np.uint64) << np.uint64(54),
+             "bottom bits only": rng.integers(0, 512, n, dtype=np.uint64),
+             "all equal": np.full(n, 0x1234567812345678 & ((1 << 63) - 1), np.uint64)}
+    for name, keys in cases.items():
+        vals = np.arange(n, dtype=np.uint32)
+        k, v = keys.copy(), vals.copy()
+        assert L.pt_debug_sort_pairs(k.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), n) == 0
+        order = np.argsort(keys, kind="stable")
+        assert np.array_equal(k, keys[order]), (name, n)
+        assert np.array_equal(v, vals[order]), (name, n)              # equal keys keep their input order
+    r.close()
+
+
+@pytest.mark.parametrize("n", [1, 255, 2048, 2049, 4196353, 9000001])
+def test_hand_written_exclusive_scan_is_numpys_cumsum(R, n):
+    """u32 exclusive scan (tiles of 2048, tile sums scanned recursively: one, two and three levels)."""
+    import ctypes as C
+    from gltf_renderer_amd.renderer import load_library
+    r = R()
+    L = load_library()
+    L.pt_debug_exclusive_scan.argtypes = [C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(n)
+    for data in (rng.integers(0, 2, n, dtype=np.uint32), rng.integers(0, 400, n, dtype=np.uint32), np.ones(n, np.uint32)):
+        d = data.copy()
+        assert L.pt_debug_exclusive_scan(d.ctypes.data_as(C.c_void_p), n) == 0
+        want = np.concatenate([[0], np.cumsum(data[:-1], dtype=np.uint64)]).astype(np.uint32)
+        assert np.array_equal(d, want), n
+    r.close()

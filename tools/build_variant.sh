@@ -12,5 +12,5 @@ for f in pt_wavefront pt_kernel accel; do
 done
 wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../variants/libmipt_$NAME.so /tmp/variant_$NAME/pt_wavefront.o /tmp/variant_$NAME/pt_kernel.o /tmp/variant_$NAME/accel.o \
-  mipt_api.o envmap.o skin_tonemap.o exchange.o host/image_decode.o host/gltf_scene.o -ldl
+  mipt_api.o sort_scan.o envmap.o skin_tonemap.o exchange.o host/image_decode.o host/gltf_scene.o -ldl
 echo built variants/libmipt_$NAME.so
