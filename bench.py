@@ -488,7 +488,7 @@ def main():
         traffic = pmc_kernels.get(dominant, {}).get("hbm_bytes_per_launch") if pmc_kernels else None
         traffic_how = "profile"
         live = None
-        if not args.no_pmc_live and binding is None and not (args.width or args.height):
+        if not args.no_pmc_live and binding is None and not (args.width or args.height or args.stage_blocks or args.cull_null_shadow):   # (the child runs the default command)
             live = pmc_live(list(kernels.keys()), spp, args.config)
             if live:
                 traffic, traffic_how = live[dominant]["hbm_bytes_per_launch"], "live"

@@ -730,7 +730,7 @@ size_t wavefront_workspace_bytes(const FrameConstants& fc, int stage_blocks) {
     const uint32_t bps = blocks_per_shard_for(stage_blocks);
     const size_t slots = state_slots_for((size_t)fc.my_tiles * kBlock * fc.spp);
     const size_t q = (size_t)kShards * seg_cap_for(fc, bps);
-    return slots * (5 * 16) + q * (4 * 16 + 4 * 16 + 16 + 2 * 16 + 2 * 2 * 16 + 2 * 4) + kCounterArrays * kShards * kCounterStride * 4 + 52 * 256;
+    return slots * (5 * 16) + q * (4 * 16 + 4 * 16 + 16 + 2 * 16 + 2 * 2 * 16 + (PT_OCC_CACHE ? 2 * 4 : 0)) + kCounterArrays * kShards * kCounterStride * 4 + 52 * 256;
 }
 
 static WfBuffers carve(void* base, const FrameConstants& fc, int stage_blocks) {
@@ -757,7 +757,7 @@ static WfBuffers carve(void* base, const FrameConstants& fc, int stage_blocks) {
     wf.env_b = (float4*)take(q * 16);
     wf.sh_o = (float4*)take(q * 2 * 16);
     wf.sh_d = (float4*)take(q * 2 * 16);
-    wf.sh_c = (uint32_t*)take(q * 2 * 4);
+    wf.sh_c = PT_OCC_CACHE ? (uint32_t*)take(q * 2 * 4) : nullptr;
     wf.occ_cache = nullptr;
     wf.capacity = slots;
     return wf;
