@@ -93,6 +93,40 @@ struct DynamicPrimitives { std::vector<DynamicMesh> meshes; };
 
 }  // namespace
 
+// Gltf::LoadCameras (Gltf.cpp:642-655) + Camera::GetViewToClip (Camera.h:80-92) for one entry of the file's `cameras` array
+static gs_camera_info parse_camera(const Value& c) {
+    gs_camera_info info;
+    gs_camera_info* o = &info;
+    memset(o, 0, sizeof(*o));
+    const std::string type = c.get("type").string_or("");
+    o->upstream_type_matches = (type == "Perspective" || type == "Orthographic") ? 1 : 0;
+    o->type = (type == "perspective" || type == "Perspective") ? 0 : ((type == "orthographic" || type == "Orthographic") ? 1 : -1);
+    double m[16] = {0};
+    if (o->type == 0) {
+        const Value& p = c.get("perspective");
+        o->aspect_ratio = (float)p.get("aspectRatio").number_or(0.0); o->y_fov = (float)p.get("yfov").number_or(0.0);
+        o->z_near = (float)p.get("znear").number_or(0.0); o->z_far = (float)p.get("zfar").number_or(0.0);
+        // Camera::GetViewToClip (Camera.h:80-88): perspectiveRH_ZO(y_fov, aspect, zNear <- far (100000 if 0), zFar <- near); SURVEY section 11
+        const double aspect = o->aspect_ratio > 0 ? o->aspect_ratio : 1.0, zn = o->z_far != 0.0f ? o->z_far : 100000.0, zf = o->z_near;
+        const double t = tan((double)o->y_fov / 2.0);
+        if (t != 0.0 && zn != zf) {
+            m[0] = 1.0 / (aspect * t); m[5] = 1.0 / t; m[10] = zf / (zn - zf); m[11] = -1.0; m[14] = -(zf * zn) / (zf - zn);
+        }
+    } else if (o->type == 1) {
+        const Value& p = c.get("orthographic");
+        o->x_mag = (float)p.get("xmag").number_or(0.0); o->y_mag = (float)p.get("ymag").number_or(0.0);
+        o->z_near = (float)p.get("znear").number_or(0.0); o->z_far = (float)p.get("zfar").number_or(0.0);
+        o->aspect_ratio = o->y_mag != 0.0f ? o->x_mag / o->y_mag : 0.0f;                 // Camera::Orthographic, Camera.h:31-40
+        // orthoRH_ZO(l = -1/xmag, r = 1/xmag, b = -1/ymag, t = 1/ymag, zNear <- far, zFar <- near) (Camera.h:91)
+        if (o->x_mag != 0.0f && o->y_mag != 0.0f && o->z_near != o->z_far) {
+            const double zn = o->z_far, zf = o->z_near;
+            m[0] = (double)o->x_mag; m[5] = (double)o->y_mag; m[10] = -1.0 / (zf - zn); m[14] = -zn / (zf - zn); m[15] = 1.0;
+        }
+    }
+    for (int k = 0; k < 16; k++) o->view_to_clip[k] = (float)m[k];
+    return info;
+}
+
 struct gs_scene {
     std::string filename, base_dir;
     Value json;
@@ -112,6 +146,7 @@ struct gs_scene {
     std::vector<pt_sampler_desc> samplers;
     std::vector<int> sampler_handles;
     int num_cameras = 0;
+    std::vector<gs_camera_info> cameras;   // Gltf::LoadCameras
     bool uploaded = false;
 
     // ---------------------------------------------------------------- accessors (TinyGltfTools.h)
@@ -860,6 +895,7 @@ struct Loader {
         for (size_t i = 0; i < sc.size(); i++)
             for (size_t k = 0; k < sc.at(i).get("nodes").size(); k++) s.scenes[i].push_back(sc.at(i).get("nodes").at(k).int_or(-1));
         s.num_cameras = (int)s.json.get("cameras").size();
+        for (int k = 0; k < s.num_cameras; k++) s.cameras.push_back(parse_camera(s.json.get("cameras").at((size_t)k)));
         if (!load_nodes()) return false;
         for (auto& roots : s.scenes) for (int n : roots) if (n < 0 || n >= (int)s.nodes.size()) { err = "glTF: scene root out of range"; return false; }
         if (!load_skins()) return false;
@@ -1092,6 +1128,13 @@ int gs_get_sampler(const gs_scene* s, int i, pt_sampler_desc* o) {
     if (!s || !o) return fail(PT_ERR_INVALID_ARGUMENT, "gs_get_sampler: null argument");
     if (i < 0 || i >= (int)s->samplers.size()) return fail(PT_ERR_BAD_HANDLE, "gs_get_sampler: index out of range");
     *o = s->samplers[i];
+    return PT_OK;
+}
+
+int gs_get_camera(const gs_scene* s, int i, gs_camera_info* o) {                       // Gltf::LoadCameras, Gltf.cpp:642-655
+    if (!s || !o) return fail(PT_ERR_INVALID_ARGUMENT, "gs_get_camera: null argument");
+    if (i < 0 || i >= (int)s->cameras.size()) return fail(PT_ERR_BAD_HANDLE, "gs_get_camera: index out of range");
+    *o = s->cameras[(size_t)i];
     return PT_OK;
 }
 

@@ -10,7 +10,7 @@ from . import abi
 from .renderer import MiptError, load_library
 
 SCENE_EXPORTS = ["gs_load_file", "gs_free", "gs_last_error", "gs_get_counts", "gs_get_primitive", "gs_get_morph_target", "gs_get_material",
-                 "gs_get_texture", "gs_get_sampler", "gs_get_node", "gs_get_node_weights", "gs_get_scene_nodes", "gs_get_skin", "gs_get_animation",
+                 "gs_get_texture", "gs_get_sampler", "gs_get_camera", "gs_get_node", "gs_get_node_weights", "gs_get_scene_nodes", "gs_get_skin", "gs_get_animation",
                  "gs_get_channel", "gs_sample_channel", "gs_apply_rest_transforms", "gs_animate", "gs_calculate_global_transforms", "gs_player_tick",
                  "gs_gather_lights", "gs_gather_bones", "gs_upload", "gs_unload", "gs_frame", "img_load_rgba8", "img_decode_rgba8", "img_load_rgb32f",
                  "img_decode_rgb32f", "img_free", "img_write_png", "img_write_pfm", "img_write_exr"]
@@ -25,6 +25,11 @@ class GsPrimitiveInfo(C.Structure):
     _fields_ = [("mesh", C.c_int), ("index_in_mesh", C.c_int), ("flags", C.c_int), ("topology", C.c_int), ("num_vertices", C.c_int), ("num_indices", C.c_int),
                 ("index_format", C.c_int), ("material_id", C.c_int), ("num_targets", C.c_int), ("index", C.c_void_p), ("position", C.c_void_p),
                 ("tangent_space", C.c_void_p), ("texcoord", C.c_void_p * 2), ("color", C.c_void_p), ("joint_weight", C.c_void_p)]
+
+
+class GsCameraInfo(C.Structure):
+    _fields_ = [("type", C.c_int), ("aspect_ratio", C.c_float), ("y_fov", C.c_float), ("x_mag", C.c_float), ("y_mag", C.c_float), ("z_near", C.c_float), ("z_far", C.c_float),
+                ("upstream_type_matches", C.c_int), ("view_to_clip", C.c_float * 16)]
 
 
 class GsNodeInfo(C.Structure):
@@ -59,7 +64,7 @@ def _lib():
         L.img_free.argtypes = [C.c_void_p]
         L.gs_free.argtypes = [C.c_void_p]
         L.gs_load_file.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
-        for name in ("gs_get_counts", "gs_get_primitive", "gs_get_material", "gs_get_sampler", "gs_get_node", "gs_get_channel"):
+        for name in ("gs_get_counts", "gs_get_primitive", "gs_get_material", "gs_get_sampler", "gs_get_camera", "gs_get_node", "gs_get_channel"):
             getattr(L, name).argtypes = None
         L.gs_sample_channel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.gs_animate.argtypes = [C.c_void_p, C.c_int, C.c_float]
@@ -155,6 +160,12 @@ class GltfScene:
         d = abi.PtSamplerDesc()
         self._ck(self.L.gs_get_sampler(self.h, C.c_int(i), C.byref(d)))
         return d
+
+    def camera(self, i):
+        """Gltf::LoadCameras: the file's camera `i` and Camera::GetViewToClip's matrix for it."""
+        c = GsCameraInfo()
+        self._ck(self.L.gs_get_camera(self.h, C.c_int(i), C.byref(c)))
+        return c
 
     def node(self, i):
         n = GsNodeInfo()

@@ -60,6 +60,23 @@ int gs_get_material(const gs_scene* s, int material, pt_material* out);
 int gs_get_texture(const gs_scene* s, int i, int* width, int* height, int* srgb, int* loaded, const uint8_t** rgba8);
 int gs_get_sampler(const gs_scene* s, int i, pt_sampler_desc* out);
 
+/* Gltf::LoadCameras (Source/Gltf.cpp:642-655) -> class Camera (Source/Camera.h).  The fields are the file's (glTF 2.0 `perspective` /
+ * `orthographic` objects); `view_to_clip` is Camera::GetViewToClip's reversed-Z matrix for them (Camera.h:80-92: perspectiveRH_ZO with near and
+ * far swapped, far == 0 -> 100000; orthoRH_ZO(-1/xmag, 1/xmag, -1/ymag, 1/ymag, far, near)), column-major, ready for pt_execute_params.
+ * Two things upstream does differently, neither observable there because the application never renders through a file's camera (it uses its
+ * orbit / free controllers, Main.cpp:515): it compares the type with "Perspective" / "Orthographic" -- the specification's values are
+ * lower-case, so a conformant file leaves its Camera objects unset (`upstream_type_matches` = 0) -- and it hands (aspectRatio, yfov, zfar, znear)
+ * to Perspective(aspect, y_fov, z_near, z_far), i.e. near and far swapped.  Neither is reproduced: there is no behaviour to match. */
+typedef struct gs_camera_info {
+    int type;                          /* 0 perspective, 1 orthographic, -1 neither */
+    float aspect_ratio, y_fov;         /* perspective (aspect_ratio 0 when the file leaves it to the viewport) */
+    float x_mag, y_mag;                /* orthographic */
+    float z_near, z_far;               /* z_far 0: infinite (perspective) */
+    int upstream_type_matches;
+    float view_to_clip[16];
+} gs_camera_info;
+int gs_get_camera(const gs_scene* s, int i, gs_camera_info* out);
+
 typedef struct gs_node_info {
     int child, sibling, mesh, skin, dynamic_mesh, camera, light;
     float rest_translation[3], rest_rotation[4] /* x y z w */, rest_scale[3];

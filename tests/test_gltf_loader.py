@@ -709,3 +709,34 @@ def test_image_writers_round_trip(tmp_path):
     assert half and np.array_equal(got, hdr.astype(np.float16).astype(np.float32))       # round to nearest even, like numpy
     with pytest.raises(MiptError):
         G.write_png(tmp_path / "no_such_dir" / "x.png", smooth)
+
+
+def test_cameras_of_the_file_and_their_reversed_z_projection(tmp_path):
+    """Gltf::LoadCameras (Gltf.cpp:642-655) + Camera::GetViewToClip (Camera.h:80-92): the file's perspective / orthographic cameras with the
+    reversed-Z matrix the path tracer is fed, against camera.py's restatement of the same closed forms; an infinite far plane becomes 100000;
+    upstream's capitalised type comparison (which no conformant file satisfies) is reported, not reproduced."""
+    from gltf_renderer_amd import camera
+    from gltf_renderer_amd.gltf import GltfScene
+    from tests.gltf_writer import Builder
+    b = Builder()
+    tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    m = b.mesh([{"attributes": {"POSITION": b.accessor(tri, minmax=True)}}])
+    b.j["cameras"] = [{"type": "perspective", "perspective": {"aspectRatio": 1.5, "yfov": 0.8, "znear": 0.05, "zfar": 250.0}},
+                      {"type": "perspective", "perspective": {"yfov": 1.1, "znear": 0.1}},                                    # infinite far plane, aspect left to the viewport
+                      {"type": "orthographic", "orthographic": {"xmag": 2.0, "ymag": 0.5, "znear": 0.01, "zfar": 40.0}},
+                      {"type": "Perspective", "perspective": {"aspectRatio": 2.0, "yfov": 0.5, "znear": 1.0, "zfar": 10.0}}]       # the spelling upstream compares with
+    b.node(root=True, mesh=m, camera=0)
+    path = b.write_glb(str(tmp_path / "cameras.glb"))
+    sc = GltfScene(path)
+    assert sc.counts().cameras == 4 and sc.node(0).camera == 0
+    c = [sc.camera(i) for i in range(4)]
+    assert [x.type for x in c] == [0, 0, 1, 0] and [x.upstream_type_matches for x in c] == [0, 0, 0, 1]
+    assert (c[0].aspect_ratio, c[0].z_far) == (1.5, 250.0) and abs(c[0].y_fov - 0.8) < 1e-7 and abs(c[0].z_near - 0.05) < 1e-8
+    assert np.allclose(np.array(c[0].view_to_clip[:]), camera.cm(camera.view_to_clip(1.5, 0.8, 0.05, 250.0)), rtol=1e-6, atol=1e-7)
+    assert c[1].z_far == 0.0 and c[1].aspect_ratio == 0.0
+    assert np.allclose(np.array(c[1].view_to_clip[:]), camera.cm(camera.view_to_clip(1.0, 1.1, 0.1, 0.0)), rtol=1e-6, atol=1e-7)     # far 0 -> 100000 (Camera.h:85-88)
+    assert (c[2].x_mag, c[2].y_mag) == (2.0, 0.5) and c[2].aspect_ratio == 4.0
+    assert np.allclose(np.array(c[2].view_to_clip[:]), camera.cm(camera.ortho_view_to_clip(2.0, 0.5, 0.01, 40.0)), rtol=1e-6, atol=1e-7)
+    with pytest.raises(Exception):
+        sc.camera(4)
+    sc.close()
