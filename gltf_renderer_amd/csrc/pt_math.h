@@ -176,6 +176,14 @@ PT_DEV float hpow(float x, float y) { return (float)exp2((double)(y * (float)log
 #else
 PT_DEV float hpow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
 #endif
+// pow with the CONSTANT integer exponents the path uses -- Schlick's (1 - |c|)^5, the punctual lights' (d / cutoff)^4 -- as products: x^2 * x^2 (* x),
+// each product correctly rounded, NaN for a negative base like the exp2 / log2 form.  HLSL leaves pow's precision to the implementation and
+// shader compilers expand such pows themselves; what matters here is that this is a definition the CPU oracle evaluates to the SAME BITS
+// (its hlsl.h: hpow5 / hpow4), which exp2(y * log2 x) through two different approximate libraries is not: Schlick's weight feeds the lobe
+// pick and Russian roulette, and a last-bit difference there flips about one pixel-sample in two million into a different path -- enough
+// fireflies, at BASELINE size and 64 samples, to bring the image metric to 8e-4 of the 1e-3 contract (tools/fullsize_parity.py).
+PT_DEV float hpow5(float x) { const float x2 = x * x; return x < 0.0f ? __builtin_nanf("") : (x2 * x2) * x; }
+PT_DEV float hpow4(float x) { const float x2 = x * x; return x < 0.0f ? __builtin_nanf("") : x2 * x2; }
 PT_DEV float max3(vec3 c) { return fmaxf(fmaxf(c.x, c.y), c.z); }
 PT_DEV bool any_gt0(vec3 v) { return v.x > 0 || v.y > 0 || v.z > 0; }
 PT_DEV bool any_nan(vec3 v) { return (v.x != v.x) || (v.y != v.y) || (v.z != v.z); }

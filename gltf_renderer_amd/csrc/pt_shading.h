@@ -618,8 +618,8 @@ PT_DEV Surface get_surface(const SceneRec& sc, uint32_t flags, const RMat* m, co
 }
 
 // ---------------------------------------------------------------- BSDF terms (Bsdf.hlsli)
-PT_DEV float schlick(float f0, float c) { return f0 + (1 - f0) * hpow(1 - fabsf(c), 5); }                    // :39-42
-PT_DEV vec3 schlick3(vec3 f0, float c) { return f0 + (1 - f0) * hpow(1 - fabsf(c), 5); }                     // :44-47
+PT_DEV float schlick(float f0, float c) { return f0 + (1 - f0) * hpow5(1 - fabsf(c)); }                    // :39-42
+PT_DEV vec3 schlick3(vec3 f0, float c) { return f0 + (1 - f0) * hpow5(1 - fabsf(c)); }                     // :44-47
 PT_DEV float ggx_d(float a, float ndh) {                                                                       // :50-57
     float a2 = a * a;
     float den = ndh * ndh * (a2 - 1) + 1;
@@ -1002,7 +1002,7 @@ PT_DEV void light_ray(const pt_light& light, vec3 p, vec3& dir, vec3& color, boo
     if (local) {
         float distance = length(dir);
         float falloff = 1.0f;
-        if (light.cutoff > 0.0f) falloff = hmax(hmin(1.0f - hpow(fdiv(distance, light.cutoff), 4.0f), 1.0f), 0.0f);
+        if (light.cutoff > 0.0f) falloff = hmax(hmin(1.0f - hpow4(fdiv(distance, light.cutoff)), 1.0f), 0.0f);
         falloff = fdiv(falloff, distance * distance);
         color *= falloff;
     }

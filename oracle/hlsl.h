@@ -106,6 +106,11 @@ inline float o_sin(float x) { return (float)std::sin((double)x); }
 inline float o_cos(float x) { return (float)std::cos((double)x); }
 // pow(x,y) = exp2(y*log2(x)): x<0 -> NaN, pow(0, y>0) = 0.
 inline float hpow(float x, float y) { return exp2f(y * log2f(x)); }
+// pow with the constant integer exponents 5 (Schlick's Fresnel, Bsdf.hlsli:39-47) and 4 (the light falloff, Lights.hlsli:41) as correctly rounded
+// products, NaN for a negative base like the exp2 / log2 form: HLSL leaves pow's precision open (and shader compilers expand such pows); this is
+// the definition the HIP kernels evaluate to the same bits (csrc/pt_math.h hpow5 / hpow4) -- two approximate exp2 / log2 libraries are not.
+inline float hpow5(float x) { const float x2 = x * x; return x < 0.0f ? NAN : (x2 * x2) * x; }
+inline float hpow4(float x) { const float x2 = x * x; return x < 0.0f ? NAN : x2 * x2; }
 inline float3 hpow(float3 v, float y) { return {hpow(v.x, y), hpow(v.y, y), hpow(v.z, y)}; }
 inline float3 habs(float3 v) { return {fabsf(v.x), fabsf(v.y), fabsf(v.z)}; }
 inline bool any_gt0(float3 v) { return v.x > 0 || v.y > 0 || v.z > 0; }

@@ -179,7 +179,7 @@ inline LightRay GetLightRay(const Light& light, float3 p) {         // :26-61
     if (light.type == 0 || light.type == 1) {
         float distance = length(ray.direction);
         float falloff = 1.0f;
-        if (light.cutoff > 0.0f) falloff = hmax(hmin(1.0f - hpow(distance / light.cutoff, 4.0f), 1.0f), 0.0f);
+        if (light.cutoff > 0.0f) falloff = hmax(hmin(1.0f - hpow4(distance / light.cutoff), 1.0f), 0.0f);
         falloff /= distance * distance;
         ray.color *= falloff;
     }
@@ -208,8 +208,8 @@ static const float MINIMUM_ROUGHNESS = 0.001f;                      // :26
 
 inline float Heavyside(float a) { return a > 0 ? 1.f : 0.f; }       // :29-32
 inline float MaxValue(float3 c) { return hmax(hmax(c.x, c.y), c.z); }  // :34-37
-inline float SchlickFresnel(float f0, float ndv) { return f0 + (1 - f0) * hpow(1 - fabsf(ndv), 5); }      // :39-42
-inline float3 SchlickFresnel(float3 f0, float ndv) { return f0 + (1 - f0) * hpow(1 - fabsf(ndv), 5); }   // :44-47
+inline float SchlickFresnel(float f0, float ndv) { return f0 + (1 - f0) * hpow5(1 - fabsf(ndv)); }      // :39-42
+inline float3 SchlickFresnel(float3 f0, float ndv) { return f0 + (1 - f0) * hpow5(1 - fabsf(ndv)); }   // :44-47
 inline float GgxD(float a, float ndh) {                             // :50-57
     float a2 = a * a;
     float num = a2 * Heavyside(ndh);
