@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256) void k_seg_pass(const TriPacket* __restrict__ 
         if (LEAVES) {
             const TriPacket& tp = tris[e];
             const vec3 p = v3p(tp.v0), q = p + v3p(tp.e1), r = p + v3p(tp.e2);
+            // (this expression for the box is also the traversal's, pt_traverse.h candidate_stands: a hit must pass the box test of its own box)
             const vec3 lo = hmin(hmin(p, q), r), hi = hmax(hmax(p, q), r);
             b[0] = lo.x; b[1] = lo.y; b[2] = lo.z; b[3] = hi.x; b[4] = hi.y; b[5] = hi.z;
             SegBox o; o.lo[0] = b[0]; o.lo[1] = b[1]; o.lo[2] = b[2]; o._a = 0; o.hi[0] = b[3]; o.hi[1] = b[4]; o.hi[2] = b[5]; o._b = 0;

@@ -864,6 +864,35 @@ extern "C" int pt_debug_interleaved_emissive(const pt_ctx* ctx) {          // ..
     return n;
 }
 
+// test hook (not part of include/mipt.h): what the product's traversal finds for caller-supplied rays (host arrays: 8 floats per ray in,
+// 8 floats per ray out, pt_kernel.hip k_debug_intersect).  mode 0 = TraceRay's closest hit, 1 = TraceShadowRay's occlusion search.
+extern "C" int pt_debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, uint32_t ray_flags, int mode, float* out) {
+    if (!ctx || (n && (!rays || !out)) || mode < 0 || mode > 1) return PT_ERR_INVALID_ARGUMENT;
+    ENTER(ctx);
+    if (ctx->accel_state != ACCEL_CLEAN || !ctx->accel_built || ctx->instances_dirty) { int r = Pathtracer::BuildAccel(ctx); if (r) return r; }
+    if (n == 0) return PT_OK;
+    SceneRec sc;
+    memset(&sc, 0, sizeof(sc));
+    sc.rmats = ctx->d_rmats; sc.lights = ctx->d_lights; sc.instances = ctx->d_instances;
+    sc.n_materials = (uint32_t)ctx->n_materials; sc.n_instances = (uint32_t)ctx->instances.size();
+    sc.nodes = ctx->d_nodes; sc.tris = ctx->d_tris; sc.shade = ctx->d_shade; sc.root = ctx->root; sc.num_tris = ctx->n_tris;
+    sc.sheen_e = ctx->d_sheen; sc.srgb_lut = ctx->d_srgb; sc.tangent_lut = ctx->d_tangent_lut;
+    const uint32_t lanes = (n + 255u) & ~255u;
+    float *d_rays = nullptr, *d_out = nullptr; int32_t* d_deep = nullptr;
+    auto done = [&](int code, const std::string& why) { hipFree(d_rays); hipFree(d_out); hipFree(d_deep); return code == PT_OK ? PT_OK : ctx->fail(code, why); };
+    if (hipMalloc((void**)&d_rays, (size_t)n * 32) != hipSuccess || hipMalloc((void**)&d_out, (size_t)n * 32) != hipSuccess) { (void)hipGetLastError(); return done(PT_ERR_OUT_OF_MEMORY, "pt_debug_intersect: ray buffers"); }
+    if ((int)ctx->stack_need > traversal_stack_capacity()) {
+        const uint32_t entries = (ctx->stack_need - (uint32_t)traversal_stack_capacity() + 7u) & ~7u;
+        if (hipMalloc((void**)&d_deep, (size_t)entries * lanes * 4) != hipSuccess) { (void)hipGetLastError(); return done(PT_ERR_OUT_OF_MEMORY, "pt_debug_intersect: deep stack"); }
+        sc.deep_stack = d_deep; sc.deep_entries = entries; sc.deep_lanes = lanes;
+    }
+    hipError_t e = hipMemcpyAsync(d_rays, rays, (size_t)n * 32, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) { launch_debug_intersect(sc, d_rays, n, ray_flags, mode, d_out, ctx->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    return done(e == hipSuccess ? PT_OK : PT_ERR_DEVICE, std::string("pt_debug_intersect: ") + hipGetErrorString(e));
+}
+
 int pt_scene_set_lights(pt_ctx* ctx, const pt_light* l, int count) {
     if (!ctx || (count > 0 && !l) || count < 0) return PT_ERR_INVALID_ARGUMENT;
     ENTER(ctx);

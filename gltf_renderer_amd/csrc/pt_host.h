@@ -104,6 +104,7 @@ struct StageTimers {
     std::vector<uint8_t> kind;           // STAGE_* of the k-th launch
     size_t used = 0;                     // launches recorded by the last pt_trace
 };
+void launch_debug_intersect(const SceneRec& sc, const float* d_rays, uint32_t n, uint32_t rf, int mode, float* d_out, hipStream_t stream);
 void launch_megakernel(const SceneRec& sc, const FrameConstants& fc, float4* output, Counters* counters, bool count, hipStream_t stream);
 size_t wavefront_workspace_bytes(const FrameConstants& fc, int stage_blocks);
 // occ_cache: the context's occluder cache (res_x * res_y * 8 words, persistent across calls; nullptr = none), see WfBuffers::occ_cache

@@ -114,6 +114,29 @@ void launch_megakernel(const SceneRec& sc, const FrameConstants& fc, float4* out
     else hipLaunchKernelGGL(pt_megakernel<false>, grid, block, 0, stream, sc, fc, output, counters);
 }
 
+// Test hook (pt_debug_intersect): the product's traversal on caller-supplied rays, one ray per lane -- what TraceRay / TraceShadowRay find,
+// without the shading around them.  rays: 8 floats each (origin, tmin, direction, tmax); out: 8 floats each (committed, t, u, v, instance,
+// primitive, front face, transmission).
+__global__ __launch_bounds__(kBlock) void k_debug_intersect(SceneRec sc, const float* __restrict__ rays, uint32_t n, uint32_t rf, int mode, float* __restrict__ out) {
+    __shared__ int s_stack[kStackLds * kBlock];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float* q = rays + (size_t)i * 8;
+    Ray r; r.o = v3(q[0], q[1], q[2]); r.tmin = q[3]; r.d = v3(q[4], q[5], q[6]); r.tmax = q[7];
+    HitRec hit; LaneStats st = {0, 0, 0, 0, 0};
+    float transmission = (mode == 1 && (rf & RF_FORCE_NON_OPAQUE)) ? 1.0f : 0.0f;
+    const bool got = traverse<false>(sc, s_stack + threadIdx.x, r, rf, 0xff, mode, hit, transmission, st);
+    float* o = out + (size_t)i * 8;
+    const bool have = got && hit.tri >= 0;
+    o[0] = got ? 1.0f : 0.0f; o[1] = have ? hit.t : 0.0f; o[2] = have ? hit.u : 0.0f; o[3] = have ? hit.v : 0.0f;
+    o[4] = have ? (float)sc.tris[hit.tri].inst : -1.0f; o[5] = have ? (float)sc.tris[hit.tri].prim : -1.0f; o[6] = (have && hit.front) ? 1.0f : 0.0f;
+    o[7] = transmission;
+}
+void launch_debug_intersect(const SceneRec& sc, const float* d_rays, uint32_t n, uint32_t rf, int mode, float* d_out, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_debug_intersect, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sc, d_rays, n, rf, mode, d_out);
+}
+
 // (sin, cos) table of the packed tangent angle, filled by the decoder's own expression (pt_shading.h)
 __global__ __launch_bounds__(256) void k_tangent_lut(float2* __restrict__ out) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;

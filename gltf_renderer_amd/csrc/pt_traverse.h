@@ -40,6 +40,12 @@ namespace pt {
 // million then missed a box whose triangle it hits (a wall's box has no thickness), left the scene through the wall and came back as a
 // firefly: 43 pixels of a 64-sample frame beyond 1e-2 of the CPU oracle's, image metric 7.9e-4 of the 1e-3 allowed; subtracting first: 2 pixels,
 // 4.0e-5, and the frame time is the same (22.7 against 22.8 ms: the traversal waits on its node loads, not on these instructions).
+#ifndef PT_TIE_BREAK
+#define PT_TIE_BREAK 1
+#endif
+#ifndef PT_BOX_GATE
+#define PT_BOX_GATE 1
+#endif
 #ifndef PT_SLAB_SUBTRACT_FIRST
 #define PT_SLAB_SUBTRACT_FIRST 1
 #endif
@@ -270,6 +276,33 @@ PT_DEV void trav_node_step(Trav& t, const SceneRec& sc, int* lds_stack, int* spi
 }
 #endif
 
+// What makes the answer independent of the TREE (rare path: only for a triangle the float Moeller-Trumbore test has just accepted).
+//  (1) The box gate.  The float test does not decide "inside" exactly: it accepts rays that pass a few ulp (of the ray's length, more at
+//      grazing incidence) outside the triangle, hence sometimes outside the triangle's box, and whether a tree's boxes cull such a ray
+//      before the triangle is asked depends on the tree -- two trees (this one, the CPU oracle's binary one) then disagree on about one ray
+//      in 10^8, each a different path: fireflies.  So a candidate also has to pass the box test of ITS OWN box, in the node test's
+//      arithmetic, and its distance has to be consistent with that box.  Every ancestor's box contains the triangle's (the builder checks
+//      the dequantised planes against it), each operation of the box test is monotone in the plane under float rounding, so an ancestor
+//      passes whenever the triangle's own box does: no tree culls a candidate that stands, and none is asked about one that does not.
+//  (2) The tie rule.  Two triangles at EXACTLY the same distance (coplanar, overlapping surfaces): DXR leaves the winner to the order of the
+//      walk; here the lower (instance, primitive) wins.
+// The oracle states both the same way (oracle.cpp Tracer::intersect), and its exhaustive search over all triangles finds the same hits.
+PT_DEV bool candidate_stands(const Trav& t, const SceneRec& sc, vec3 v0, vec3 e1, vec3 e2, float tt, float limit, uint32_t inst, uint32_t prim) {
+    if (PT_BOX_GATE) {
+        const vec3 v1 = v0 + e1, v2 = v0 + e2;                                          // the builder's expression for the box (accel.hip k_seg_pass)
+        const vec3 lo = hmin(hmin(v0, v1), v2), hi = hmax(hmax(v0, v1), v2);
+        const float a0 = (lo.x - t.o.x) * t.inv.x, b0 = (hi.x - t.o.x) * t.inv.x, a1 = (lo.y - t.o.y) * t.inv.y, b1 = (hi.y - t.o.y) * t.inv.y;
+        const float a2 = (lo.z - t.o.z) * t.inv.z, b2 = (hi.z - t.o.z) * t.inv.z;
+        const float tn = fmaxf(fmaxf(fminf(a0, b0), fminf(a1, b1)), fmaxf(fminf(a2, b2), t.tmin));
+        const float tx = fminf(fminf(fmaxf(a0, b0), fmaxf(a1, b1)), fmaxf(a2, b2));
+        if (!(tn <= tx * 1.0000004f && tn <= tt * 1.0000004f)) return false;
+    }
+    if (tt < limit) return true;
+    if (!(PT_TIE_BREAK && t.mode == 0 && t.best.tri >= 0)) return false;                // tt == limit: the interval's end, or a tie with the hit held
+    const uint4 h0 = *(const uint4*)((const float4*)sc.tris + (size_t)t.best.tri * 3), h1 = *(const uint4*)((const float4*)sc.tris + (size_t)t.best.tri * 3 + 1);
+    return inst < h0.w || (inst == h0.w && prim < h1.w);
+}
+
 // One leaf step: t.cur = leaf reference (1..kLeafMax contiguous triangles) on entry; on exit the popped entry or kTravDone.
 // `keep` != kTravDone: the leaf tested is a POSTPONED one (trace_persistent): instead of popping, the lane goes on with `keep`, the entry it
 // had already moved on to -- unless the ray ended in this leaf.
@@ -301,7 +334,8 @@ PT_DEV void trav_leaf_step(Trav& t, const SceneRec& sc, const int* lds_stack, co
         float v = dot(t.d, q) * invd;
         float tt = dot(e2, q) * invd;
         float limit = t.all_candidates ? t.tmax : t.best.t;
-        bool ok = (u >= 0.0f) && (u <= 1.0f) && (v >= 0.0f) && (u + v <= 1.0f) && (tt > t.tmin) && (tt < limit);
+        bool ok = (u >= 0.0f) && (u <= 1.0f) && (v >= 0.0f) && (u + v <= 1.0f) && (tt > t.tmin) && (tt <= limit);
+        if (ok) ok = candidate_stands(t, sc, v0, e1, e2, tt, limit, __float_as_uint(q0.w), __float_as_uint(q1.w));
         if (ok && (t.mask & tflags & 0xffu)) {
             bool front = (det > 0.0f) != ((tflags & TF_MIRRORED) != 0);
             bool culled = false;

@@ -375,6 +375,10 @@ struct Oracle {
     Bvh bvh;
     bool accel_dirty = true;
     bool brute_force = false;
+    // diagnostics (tools/diag_flip.py): trace only the pixels of a window; record every ray of one pixel with what it found
+    uint32_t win[4] = {0, 0, 0xffffffffu, 0xffffffffu};             // x0, y0, x1, y1 (exclusive)
+    int64_t log_px = -1, log_py = -1;
+    std::vector<float> ray_log;                                     // 16 floats per ray: origin, tmin, direction, tmax, mode, hit, t, instance, primitive, transmission, ray flags, 0
     int bounce_limit = 5;                // Pathtracer::MAX_BOUNCES, Pathtracer.h:102
     // cross-frame state of Pathtracer (Pathtracer.h:152-153)
     float previous_world_to_clip[16] = {0};
@@ -603,19 +607,36 @@ struct Tracer {
     const EnvMap* env;
 
     // Ray/triangle: Moeller-Trumbore on world-space (v0, e1, e2); hit interval tmin < t < tmax.
-    inline bool intersect(const Tri& t, const RayDesc& r, float tmax, float& ot, float& ou, float& ov, bool& front) const {
+    // Moeller-Trumbore in float, plus the two rules that make the answer independent of the tree that is walked (csrc/pt_traverse.h
+    // candidate_stands states them the same way; the exhaustive search `brute_force` and the LBVH below then find the same hits, which
+    // tests/test_gpu_round3.py checks ray by ray):
+    //  * the box gate: the float test accepts rays that pass a few ulp outside the triangle, sometimes outside its box, and a tree may or may
+    //    not have culled such a ray before the triangle is asked.  A candidate therefore has to pass the node test's box arithmetic on ITS OWN
+    //    box (tri_bounds), with a distance consistent with it; every ancestor box contains that box and the test is monotone in the planes,
+    //    so no ancestor culls a candidate that stands;
+    //  * tie_with: the triangle that holds the current closest hit at distance tmax (or null): a candidate at EXACTLY that distance replaces
+    //    it when its (instance, primitive) is lower -- DXR leaves equal distances to the traversal order.
+    inline bool intersect(const Tri& t, const RayDesc& r, const float3& inv, float tmax, float& ot, float& ou, float& ov, bool& front, const Tri* tie_with = nullptr) const {
         float3 p = cross(r.direction, t.e2);
         float det = dot(t.e1, p);
         if (det == 0.0f || !(det == det)) return false;
-        float inv = 1.0f / det;
+        float invd = 1.0f / det;
         float3 tv = r.origin - t.v0;
-        float u = dot(tv, p) * inv;
+        float u = dot(tv, p) * invd;
         if (!(u >= 0.0f) || u > 1.0f) return false;
         float3 q = cross(tv, t.e1);
-        float v = dot(r.direction, q) * inv;
+        float v = dot(r.direction, q) * invd;
         if (!(v >= 0.0f) || u + v > 1.0f) return false;
-        float tt = dot(t.e2, q) * inv;
-        if (!(tt > r.tmin) || !(tt < tmax)) return false;
+        float tt = dot(t.e2, q) * invd;
+        if (!(tt > r.tmin) || !(tt <= tmax)) return false;
+        float3 lo, hi; tri_bounds(t, lo, hi);
+        float3 t0 = (lo - r.origin) * inv, t1 = (hi - r.origin) * inv;
+        float tn = hmax(hmax(hmin(t0.x, t1.x), hmin(t0.y, t1.y)), hmax(hmin(t0.z, t1.z), r.tmin));
+        float tx = hmin(hmin(hmax(t0.x, t1.x), hmax(t0.y, t1.y)), hmax(t0.z, t1.z));
+        if (!(tn <= tx * 1.0000004f && tn <= tt * 1.0000004f)) return false;
+        if (!(tt < tmax)) {
+            if (!(tie_with && (t.inst < tie_with->inst || (t.inst == tie_with->inst && t.prim < tie_with->prim)))) return false;
+        }
         ot = tt; ou = u; ov = v;
         front = (det > 0.0f) != ((t.flags & 1) != 0);      // object-space winding (mirrored instances flip)
         return true;
@@ -652,7 +673,10 @@ struct Tracer {
         best.t = r.tmax; best.tri = -1;
         if (mask == 0 || o.bvh.tris.empty()) return false;
         bool committed = false, stop = false;
-        float3 inv = {1.0f / r.direction.x, 1.0f / r.direction.y, 1.0f / r.direction.z};
+        // 1 / direction clamped to +-1e30: with an infinite reciprocal (a direction component that is exactly zero) an origin that lies ON a box
+        // plane gives 0 * inf = NaN and the ray misses a box it is inside of (the HIP traversal clamps the same way, pt_traverse.h trav_init)
+        auto rcp = [](float d) { return hmax(hmin(1.0f / d, 1.0e30f), -1.0e30f); };
+        float3 inv = {rcp(r.direction.x), rcp(r.direction.y), rcp(r.direction.z)};
         uint64_t nn = 0, nt = 0;
         auto test_tri = [&](int ti) {
             const Tri& t = o.bvh.tris[ti];
@@ -661,7 +685,7 @@ struct Tracer {
             // alpha-shadow rays visit every candidate in the ORIGINAL interval (a DXR-conformant
             // far-to-near order; quirk q12), all other rays shrink the interval on commit.
             bool all_candidates = (mode == 1) && (ray_flags & RAY_FLAG_FORCE_NON_OPAQUE);
-            if (!intersect(t, r, all_candidates ? r.tmax : best.t, tt, u, v, front)) return;
+            if (!intersect(t, r, inv, all_candidates ? r.tmax : best.t, tt, u, v, front, (mode == 0 && best.tri >= 0) ? &o.bvh.tris[best.tri] : nullptr)) return;
             const InstanceDesc& id = o.instances[t.inst];
             if (!(mask & id.instance_mask)) return;
             if (!(id.instance_flags & INSTANCE_FLAG_TRIANGLE_CULL_DISABLE)) {
@@ -709,6 +733,12 @@ struct Tracer {
         }
         t_tally.nodes += nn;
         t_tally.tris += nt;
+        if ((int64_t)px == o.log_px && (int64_t)py == o.log_py) {
+            const bool got = committed && best.tri >= 0;
+            const float rec[16] = {r.origin.x, r.origin.y, r.origin.z, r.tmin, r.direction.x, r.direction.y, r.direction.z, r.tmax, (float)mode, committed ? 1.f : 0.f,
+                                   got ? best.t : 0.f, got ? (float)o.bvh.tris[best.tri].inst : -1.f, got ? (float)o.bvh.tris[best.tri].prim : -1.f, transmission, (float)ray_flags, 0.f};
+            o.ray_log.insert(o.ray_log.end(), rec, rec + 16);
+        }
         return committed;
     }
 
@@ -1018,8 +1048,8 @@ static void pathtrace_scene(Oracle& o, const Settings& s, const ExecuteParams& e
                 if (t >= ntiles) break;
                 if (t % nrank != rank) continue;
                 uint32_t tx = t % tiles_x, ty = t / tiles_x;
-                for (uint32_t y = ty * 16; y < std::min(ty * 16 + 16, ep.height); y++)
-                    for (uint32_t x = tx * 16; x < std::min(tx * 16 + 16, ep.width); x++) {
+                for (uint32_t y = std::max(ty * 16, o.win[1]); y < std::min(std::min(ty * 16 + 16, ep.height), o.win[3]); y++)
+                    for (uint32_t x = std::max(tx * 16, o.win[0]); x < std::min(std::min(tx * 16 + 16, ep.width), o.win[2]); x++) {
                         Tracer tr{o, sc, x, y, env};
                         tr.RayGeneration((float*)ep.output);
                     }
@@ -1271,6 +1301,19 @@ void orc_env_read(void* h, int env, uint16_t* cube_rgba16f, float* pyramid) {
 }
 void orc_set_bounce_limit(void* h, int limit) { ((Oracle*)h)->bounce_limit = limit; }
 void orc_set_brute_force(void* h, int on) { ((Oracle*)h)->brute_force = on != 0; }
+// diagnostics: restrict orc_trace to a pixel window (x1 = 0: whole frame); log the rays of one pixel (x < 0: off) and read the log back
+void orc_set_window(void* h, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
+    Oracle* o = (Oracle*)h;
+    if (x1 == 0) { o->win[0] = o->win[1] = 0; o->win[2] = o->win[3] = 0xffffffffu; }
+    else { o->win[0] = x0; o->win[1] = y0; o->win[2] = x1; o->win[3] = y1; }
+}
+void orc_set_ray_log(void* h, int x, int y) { Oracle* o = (Oracle*)h; o->log_px = x; o->log_py = y; o->ray_log.clear(); }
+int orc_read_ray_log(void* h, float* out, int max_rays) {
+    Oracle* o = (Oracle*)h;
+    const int n = (int)std::min<size_t>(o->ray_log.size() / 16, (size_t)std::max(max_rays, 0));
+    if (out && n) memcpy(out, o->ray_log.data(), (size_t)n * 16 * sizeof(float));
+    return (int)(o->ray_log.size() / 16);
+}
 void orc_build_accel(void* h) { build_accel(*(Oracle*)h); }
 // the same tree built on `nthreads` cores (bench.py cpu_baseline leg B2); 1 = the build above
 void orc_build_accel_mt(void* h, int nthreads) { build_accel(*(Oracle*)h, nthreads); }
@@ -1359,12 +1402,40 @@ void orc_mat4_inverse(const float* m, float* out) { mat4_inverse(m, out); }
 void orc_intersect(void* h, const float* origin, const float* dir, float tmin, float tmax, uint32_t ray_flags, float* out7) {
     Oracle* o = (Oracle*)h;
     if (o->accel_dirty) build_accel(*o);
-    SceneConstants sc{}; Tracer tr{*o, sc, 0, 0, nullptr};
+    SceneConstants sc{}; Tracer tr{*o, sc, 0xffffffffu, 0xffffffffu, nullptr};
     RayDesc r = {{origin[0], origin[1], origin[2]}, tmin, {dir[0], dir[1], dir[2]}, tmax};
     Hit hit; float dummy = 0;
     bool got = tr.traverse(r, ray_flags, 0xff, 0, hit, dummy);
     merge_tally(o->counters);
     out7[0] = got ? 1.f : 0.f;
     if (got) { const Tri& t = o->bvh.tris[hit.tri]; out7[1] = hit.t; out7[2] = hit.u; out7[3] = hit.v; out7[4] = (float)t.inst; out7[5] = (float)t.prim; out7[6] = hit.front ? 1.f : 0.f; }
+}
+// many rays at once on `nthreads` cores (rays: 8 floats each, origin tmin direction tmax; out: 8 floats each, committed t u v instance
+// primitive front transmission); mode 0 = TraceRay's search, 1 = TraceShadowRay's
+void orc_intersect_many(void* h, const float* rays, int n, uint32_t ray_flags, int mode, float* out, int nthreads) {
+    Oracle* o = (Oracle*)h;
+    if (o->accel_dirty) build_accel(*o);
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+        SceneConstants sc{}; Tracer tr{*o, sc, 0xffffffffu, 0xffffffffu, nullptr};
+        for (;;) {
+            const int b = next.fetch_add(1024);
+            if (b >= n) break;
+            for (int i = b; i < std::min(n, b + 1024); i++) {
+                const float* q = rays + (size_t)i * 8;
+                RayDesc r = {{q[0], q[1], q[2]}, q[3], {q[4], q[5], q[6]}, q[7]};
+                Hit hit; float transmission = (mode == 1 && (ray_flags & RAY_FLAG_FORCE_NON_OPAQUE)) ? 1.0f : 0.0f;
+                const bool got = tr.traverse(r, ray_flags, 0xff, mode, hit, transmission);
+                const bool have = got && hit.tri >= 0;
+                float* w = out + (size_t)i * 8;
+                w[0] = got ? 1.f : 0.f; w[1] = have ? hit.t : 0.f; w[2] = have ? hit.u : 0.f; w[3] = have ? hit.v : 0.f;
+                w[4] = have ? (float)o->bvh.tris[hit.tri].inst : -1.f; w[5] = have ? (float)o->bvh.tris[hit.tri].prim : -1.f; w[6] = (have && hit.front) ? 1.f : 0.f;
+                w[7] = transmission;
+            }
+        }
+        merge_tally(o->counters);
+    };
+    if (nthreads <= 1) worker();
+    else { std::vector<std::thread> th; for (int t = 0; t < nthreads; t++) th.emplace_back(worker); for (auto& t : th) t.join(); }
 }
 }

@@ -49,6 +49,12 @@ def lib():
         L.orc_env_read.restype = None
         L.orc_set_bounce_limit.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_brute_force.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_window.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.orc_set_window.restype = None
+        L.orc_set_ray_log.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_set_ray_log.restype = None
+        L.orc_read_ray_log.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_read_ray_log.restype = C.c_int
         L.orc_skin_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_trace.restype = None
@@ -184,6 +190,21 @@ class Oracle:
     def set_brute_force(self, on):
         self.L.orc_set_brute_force(self.h, int(on))
 
+    def set_window(self, x0=0, y0=0, x1=0, y1=0):
+        """Diagnostics: trace() touches only the pixels x0 <= x < x1, y0 <= y < y1 (no arguments: the whole frame again)."""
+        self.L.orc_set_window(self.h, x0, y0, x1, y1)
+
+    def ray_log(self, x, y):
+        """Diagnostics: start recording every ray of pixel (x, y) (x < 0: stop)."""
+        self.L.orc_set_ray_log(self.h, x, y)
+
+    def read_ray_log(self):
+        """[n, 16] float32: origin, tmin, direction, tmax, mode (0 closest, 1 shadow), committed, t, instance, primitive, transmission, D3D12 ray flags, 0."""
+        n = self.L.orc_read_ray_log(self.h, None, 0)
+        out = np.zeros((n, 16), np.float32)
+        if n: self.L.orc_read_ray_log(self.h, out.ctypes.data, n)
+        return out
+
     def build_accel(self, nthreads=1):
         """CPU LBVH of the scene; nthreads > 1 builds the SAME tree (node for node) on that many cores."""
         if nthreads and nthreads > 1:
@@ -223,6 +244,15 @@ class Oracle:
         n, t = C.c_uint32(), C.c_uint32()
         self.L.orc_bvh_info(self.h, C.byref(n), C.byref(t))
         return n.value, t.value
+
+    def intersect_many(self, rays, ray_flags=0, mode=0, nthreads=None):
+        """rays [n, 8] (origin, tmin, direction, tmax) -> [n, 8] (committed, t, u, v, instance, primitive, front, transmission)."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        out = np.zeros((len(rays), 8), np.float32)
+        self.L.orc_intersect_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_int]
+        self.L.orc_intersect_many.restype = None
+        self.L.orc_intersect_many(self.h, rays.ctypes.data, len(rays), ray_flags, mode, out.ctypes.data, nthreads or os.cpu_count() or 1)
+        return out
 
     def intersect(self, origin, direction, tmin=0.0, tmax=1e30, ray_flags=0):
         o, d = _f(origin), _f(direction)

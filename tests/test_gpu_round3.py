@@ -561,3 +561,40 @@ def test_hand_written_exclusive_scan_is_numpys_cumsum(R, n):
         want = np.concatenate([[0], np.cumsum(data[:-1], dtype=np.uint64)]).astype(np.uint32)
         assert np.array_equal(d, want), n
     r.close()
+
+
+# ---- the traversal alone: ray by ray against the oracle's ---------------------------------------------------------------------------
+@pytest.mark.parametrize("scene", ["sponza", "grid"])
+def test_traversal_finds_the_oracles_hit_for_every_ray(R, scene):
+    """pt_debug_intersect (the product's traversal, no shading) against the oracle's traversal: two different trees (4-wide quantised PLOC
+    against a binary float LBVH), the same triangle test, and DXR's rule that the closest hit wins -- so every ray must report the same
+    triangle with bit-identical t, u, v.  This is the test that would have caught the box test that lost rays starting far from the
+    coordinate origin (pt_traverse.h PT_SLAB_SUBTRACT_FIRST).  Two rules, stated the same way on both sides, make the hit independent of the
+    tree (pt_traverse.h candidate_stands): a candidate must pass the box test of its own box (the float triangle test accepts rays a few ulp
+    outside the triangle, which a tree may or may not have culled), and of two triangles at exactly the same distance (the stand-in scenes
+    have coplanar, overlapping surfaces: 7 rays in 10 000 here) the lower (instance, primitive) wins."""
+    from oracle import pyoracle
+    from ray_hook import gpu_intersect, dxr_flags, surface_rays, RF_CULL_BACK, RF_ACCEPT_FIRST
+    s = scenes.sponza_class(width=64, height=36, tex=64) if scene == "sponza" else scenes.material_grid(64, 36)
+    r = R(); s.upload(r)
+    o = pyoracle.Oracle(); s.upload(o)
+    first, second = surface_rays(o, s, 400_000, 5)
+    assert len(second) > 50_000
+    for rays, flags in ((first, 0), (second, 0), (second, RF_CULL_BACK)):
+        g = gpu_intersect(r, rays, flags, 0); c = o.intersect_many(rays, dxr_flags(flags), 0)
+        same_hit = (g[:, 0] == c[:, 0])
+        same_tri = same_hit & (g[:, 4] == c[:, 4]) & (g[:, 5] == c[:, 5])
+        exact = same_tri & (g[:, 1].view(np.uint32) == c[:, 1].view(np.uint32)) & (g[:, 2].view(np.uint32) == c[:, 2].view(np.uint32)) & (g[:, 3].view(np.uint32) == c[:, 3].view(np.uint32))
+        tie = same_hit & ~same_tri & (g[:, 1].view(np.uint32) == c[:, 1].view(np.uint32))          # another triangle at the very same distance
+        bad = ~(exact | tie)
+        print("\n%s: %d rays, %.1f %% hit; identical %d, equal-distance ties %d, different %d" % (scene, len(rays), 100 * c[:, 0].mean(), int(exact.sum()), int(tie.sum()), int(bad.sum())))
+        for k in np.nonzero(bad)[0][:5]: print("   ray", rays[k], "gpu", g[k], "oracle", c[k])
+        assert bad.sum() == 0 and tie.sum() == 0
+    # the oracle's tree against its own exhaustive search over every triangle, on a sample
+    sub = second[:3000]
+    o.set_brute_force(True); b = o.intersect_many(sub, 0, 0); o.set_brute_force(False)
+    assert np.array_equal(b.view(np.uint32), o.intersect_many(sub, 0, 0).view(np.uint32))
+    # occlusion rays (TraceShadowRay without alpha shadows): any hit ends the search, so only "occluded or not" is defined
+    g = gpu_intersect(r, second, RF_ACCEPT_FIRST, 1); c = o.intersect_many(second, dxr_flags(RF_ACCEPT_FIRST), 1)
+    assert np.array_equal(g[:, 0], c[:, 0]), int((g[:, 0] != c[:, 0]).sum())
+    r.close(); o.close()

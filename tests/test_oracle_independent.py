@@ -520,3 +520,23 @@ def test_multi_threaded_cpu_lbvh_is_the_single_threaded_tree(oracle_lib):
     for img, nodes, tris, rays, info in res[1:]:
         assert np.array_equal(img, res[0][0]) and (nodes, tris, rays, info) == res[0][1:]
     assert res[0][4][1] > 200000                                     # the bench scene's triangle count, not a toy
+
+
+@pytest.mark.parametrize("scene", ["sponza", "grid"])
+def test_oracle_tree_finds_what_the_exhaustive_search_finds(oracle_lib, scene):
+    """The oracle's LBVH is only an accelerator: for every ray it has to return the hit that testing EVERY triangle returns -- same triangle,
+    same t, u, v to the bit.  That holds because of two rules of its triangle test (oracle.cpp Tracer::intersect): a candidate must pass the
+    box test of its own box (else a tree could cull a ray that the float test would still accept a few ulp outside the triangle), and of two
+    triangles at exactly the same distance the lower (instance, primitive) wins.  Rays as the path tracer casts them: from points ON surfaces,
+    in random, axis-aligned and grazing directions, with and without face culling."""
+    from ray_hook import surface_rays
+    s = scenes.sponza_class(width=64, height=36, tex=16) if scene == "sponza" else scenes.material_grid(64, 36)
+    o = oracle_lib.Oracle(); s.upload(o)
+    first, second = surface_rays(o, s, 60_000, 7)
+    rays = np.concatenate([first[:1500], second[:6000]])
+    for flags in (0, 0x10, 0x20):
+        o.set_brute_force(False); tree = o.intersect_many(rays, flags, 0)
+        o.set_brute_force(True); every = o.intersect_many(rays, flags, 0)
+        assert np.array_equal(tree.view(np.uint32), every.view(np.uint32)), int((tree.view(np.uint32) != every.view(np.uint32)).any(axis=1).sum())
+        assert 0.2 < tree[:, 0].mean() < 0.95
+    o.close()
