@@ -137,6 +137,41 @@ void launch_debug_intersect(const SceneRec& sc, const float* d_rays, uint32_t n,
     hipLaunchKernelGGL(k_debug_intersect, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sc, d_rays, n, rf, mode, d_out);
 }
 
+// Test hook (pt_debug_math): the kernels' own math routines on caller-supplied arguments, for the bit-for-bit comparison with the oracle's.
+// op: 0 atan2(a, b)  1 pow(a, b)  2 exp(a)  3 log2(a)  4 exp2(a)  5 sin(a)  6 cos(a)  7 a / b by fdiv  8 pow5(a)
+__global__ __launch_bounds__(256) void k_debug_math(int op, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i], y = b[i];
+    float r = 0, s, c;
+    switch (op) {
+        case 0: r = pt_atan2(x, y); break;
+        case 1: r = hpow(x, y); break;
+        case 2: r = pt_exp(x); break;
+        case 3: r = co_log2(x); break;
+        case 4: r = co_exp2(x); break;
+        case 5: pt_sincos(x, s, c); r = s; break;
+        case 6: pt_sincos(x, s, c); r = c; break;
+        case 7: r = fdiv(x, y); break;
+        case 8: r = hpow5(x); break;
+    }
+    out[i] = r;
+}
+}  // namespace pt
+extern "C" int pt_debug_math(int op, const float* a, const float* b, float* out, uint32_t n) {
+    if (n == 0) return 0;
+    float *da = nullptr, *db = nullptr, *dc = nullptr;
+    int rc = -3;
+    if (hipMalloc(&da, (size_t)n * 4) == hipSuccess && hipMalloc(&db, (size_t)n * 4) == hipSuccess && hipMalloc(&dc, (size_t)n * 4) == hipSuccess &&
+        hipMemcpy(da, a, (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(db, b, (size_t)n * 4, hipMemcpyHostToDevice) == hipSuccess) {
+        hipLaunchKernelGGL(pt::k_debug_math, dim3((n + 255) / 256), dim3(256), 0, nullptr, op, (const float*)da, (const float*)db, dc, n);
+        if (hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess && hipMemcpy(out, dc, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess) rc = 0;
+    }
+    hipFree(da); hipFree(db); hipFree(dc);
+    return rc;
+}
+namespace pt {
+
 // (sin, cos) table of the packed tangent angle, filled by the decoder's own expression (pt_shading.h)
 __global__ __launch_bounds__(256) void k_tangent_lut(float2* __restrict__ out) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;

@@ -53,8 +53,8 @@ PT_DEV vec3 xyz(vec4 v) { return {v.x, v.y, v.z}; }
 // rcp, one correction of the reciprocal, one of the quotient, then v_div_fixup for the special operands (zero, infinity, NaN).  It is
 // BIT-IDENTICAL to a / b whenever divisor, dividend and quotient are normal numbers (tools/probes/lean_div_probe.hip: 0 mismatches in
 // 8.4e9 random operand pairs over exponents -60..60).  OUTSIDE that contract it is not IEEE division, because nothing rescales the operands: a
-// quotient below 2^-126 is not correctly rounded, and a SUBNORMAL divisor (v_rcp treats it as zero: the reciprocal is infinite) returns +-inf
-// where a / b is a large finite number (1e-30 / 1e-39: inf for 1e9).  A quotient that overflows comes out +-inf like a / b, and zero, infinite
+// quotient below 2^-126 is not correctly rounded, a SUBNORMAL divisor (v_rcp treats it as zero: the reciprocal is infinite) returns +-inf
+// where a / b is a large finite number (1e-30 / 1e-39: inf for 1e9), and a divisor above 2^126 (its reciprocal is subnormal: zero) returns 0.  A quotient that overflows comes out +-inf like a / b, and zero, infinite
 // and NaN operands are repaired by v_div_fixup (measured on the MI355X: tools/probes/lean_div_probe.hip prints the cases,
 // tests/test_gpu_math.py pins them).  On the path that reaches contrib / light_pdf, the MIS ratios and the luminance clamp a subnormal pdf is
 // already a degenerate sample that sanitize_sample zeroes either way (NaN and Inf alike, PathTracer.lib.hlsl:760-766).  Where such operands
@@ -157,23 +157,92 @@ PT_DEV void pt_sincos(float x, float& s, float& c) {
     s = pt_sin(x); c = pt_cos(x);
 #endif
 }
-PT_DEV float pt_atan2(float y, float x) { return atan2f(y, x); }
-PT_DEV float pt_exp(float x) { return expf(x); }
-// PT_F64_POW=1 (experiment): pow's log2 and exp2 through double as well
-#ifndef PT_F64_POW
-#define PT_F64_POW 0
+// atan2, log2, exp2 -- and through them pow and exp -- are DEFINED here, as short float kernels made of IEEE multiplies, adds and divisions in
+// a fixed order (no fused multiply-add: these translation units are compiled without contraction), which the CPU oracle states operation for
+// operation (its hlsl.h): the same bits on both sides by construction.  HLSL leaves the precision of these intrinsics to the implementation;
+// these are within 1.3 (atan), 2.9 (log2) and 1.2 (exp2) ulp (tools/fit_transcendentals.py fits and measures them).  Why not the library's:
+// v_exp_f32 / v_log_f32 / ocml's atan2f and glibc's routines differ in the last bit in several percent of their results.  atan2 sits in the
+// direction -> importance-map texel mapping of the environment pdf (a last bit picks the neighbouring texel once in ~10^6 lookups: a MIS
+// weight off by up to a percent), pow and exp in the sheen lobe (five pows and two exps per evaluation).  Through double (like sin / cos)
+// they cost 7.7 ms of a 22.6 ms launch (measured: ocml's double atan2, log2, exp2 are long).  These: atan2 nothing measurable; pow / exp
+// 0.8 ms on the Sponza-class scene, whose curtains (3 % of the hits) put a sheen lane into most waves of the shade stage -- v_log_f32 /
+// v_exp_f32 were 3 instructions per pow, this is ~45 (as real calls instead of inlined: 1.0 ms).  PT_CO_TRANSCENDENTALS / PT_CO_ATAN2 /
+// PT_CO_POW = 0: the library routines (A/B).
+#ifndef PT_CO_TRANSCENDENTALS
+#define PT_CO_TRANSCENDENTALS 1
 #endif
-// pow(x, y) = exp2(y * log2 x).  The library's exp2f / log2f are v_exp_f32 / v_log_f32 wrapped in range scaling for
-// subnormal arguments and results (9 + 8 instructions); the bare instructions give the same bits everywhere else and flush those to
-// zero -- Schlick's (1 - c)^5 below 2^-126.  PT_LIBM_POW=1 keeps the library calls (A/B, tools/compare_builds.py).
-#ifndef PT_LIBM_POW
-#define PT_LIBM_POW 0
+PT_DEV float co_atan2(float y, float x) {
+    if (!(x == x) || !(y == y)) return __builtin_nanf("");
+    const float ax = fabsf(x), ay = fabsf(y), mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float a;
+    if (mx == 0.0f) a = 0.0f;
+    else if (mx == __builtin_inff()) a = mn == __builtin_inff() ? 1.0f : 0.0f;
+    else a = mn / mx;                                        // the compiler's correctly rounded division
+    const float s = a * a;
+    float q = -0x1.40bebap-9f;
+    q = q * s + 0x1.c293dap-7f; q = q * s + -0x1.2920fep-5f; q = q * s + 0x1.0168bap-4f; q = q * s + -0x1.634104p-4f;
+    q = q * s + 0x1.c41dd4p-4f; q = q * s + -0x1.246facp-3f; q = q * s + 0x1.999860p-3f; q = q * s + -0x1.555554p-2f;
+    float r = a + a * (s * q);                               // atan(a), a in [0, 1]
+    if (ay > ax) r = 1.57079637f - r;
+    if (__float_as_uint(x) >> 31) r = 3.14159274f - r;
+    return copysignf(r, y);
+}
+PT_DEV float co_log2(float x) {
+    if (!(x > 0.0f)) return x == 0.0f ? -__builtin_inff() : __builtin_nanf("");
+    if (x == __builtin_inff()) return x;
+    int e = 0;
+    if (x < 1.17549435e-38f) { x *= 16777216.0f; e = -24; }  // subnormal
+    const uint32_t b = __float_as_uint(x);
+    e += (int)(b >> 23) - 127;
+    float m = __uint_as_float((b & 0x007fffffu) | 0x3f800000u);   // [1, 2)
+    if (m > 1.41421354f) { m *= 0.5f; e += 1; }              // (sqrt 1/2, sqrt 2]
+    const float t = (m - 1.0f) / (m + 1.0f), s = t * t;
+    float q = 0x1.ba1838p-2f;
+    q = q * s + 0x1.274720p-1f; q = q * s + 0x1.ec70e6p-1f; q = q * s + 0x1.715476p+1f;
+    return (float)e + t * q;
+}
+PT_DEV float co_exp2_reduced(float r) {                       // 2^r, r in [-1/2, 1/2]
+    float q = 0x1.444004p-13f;
+    q = q * r + 0x1.5f0896p-10f; q = q * r + 0x1.3b2a1cp-7f; q = q * r + 0x1.c6af6cp-5f; q = q * r + 0x1.ebfbe0p-3f; q = q * r + 0x1.62e430p-1f;
+    return 1.0f + r * q;
+}
+PT_DEV float co_scale2(float v, float n) {                       // v * 2^n, n an integer in [-125, 128]: two exact factors (2^128 is not a float)
+    const int k = (int)n, h = k / 2, g = k - h;
+    return v * __uint_as_float((uint32_t)(h + 127) << 23) * __uint_as_float((uint32_t)(g + 127) << 23);
+}
+PT_DEV float co_exp2(float p) {
+    if (!(p == p)) return p;
+    if (p >= 128.0f) return __builtin_inff();
+    if (p < -125.0f) return 0.0f;                            // results below the normal range are zero
+    const float n = rintf(p);
+    return co_scale2(co_exp2_reduced(p - n), n);                // (p - n is exact)
+}
+// e^x: n = round(x / ln 2), r = x - n ln 2 with ln 2 in two parts (the first has 11 trailing zero bits: n times it is exact), e^r = 2^(r / ln 2)
+PT_DEV float co_exp(float x) {
+    if (!(x == x)) return x;
+    if (x > 88.75f) return __builtin_inff();
+    if (x < -86.5f) return 0.0f;
+    const float n = rintf(x * 1.44269504f);
+    const float r = (x - n * 0.693145751953125f) - n * 1.42860677e-06f;
+    return co_scale2(co_exp2_reduced(r * 1.44269504f), n);
+}
+#ifndef PT_CO_ATAN2
+#define PT_CO_ATAN2 PT_CO_TRANSCENDENTALS
 #endif
-#if PT_LIBM_POW
-PT_DEV float hpow(float x, float y) { return exp2f(y * log2f(x)); }
-#elif PT_F64_POW
-PT_DEV float hpow(float x, float y) { return (float)exp2((double)(y * (float)log2((double)x))); }
+#ifndef PT_CO_POW
+#define PT_CO_POW PT_CO_TRANSCENDENTALS
+#endif
+#if PT_CO_ATAN2
+PT_DEV float pt_atan2(float y, float x) { return co_atan2(y, x); }
 #else
+PT_DEV float pt_atan2(float y, float x) { return atan2f(y, x); }
+#endif
+// pow(x, y) = exp2(y * log2 x): NaN for a negative base, pow(0, y > 0) = 0.
+#if PT_CO_POW
+PT_DEV float pt_exp(float x) { return co_exp(x); }
+PT_DEV float hpow(float x, float y) { return co_exp2(y * co_log2(x)); }
+#else
+PT_DEV float pt_exp(float x) { return expf(x); }
 PT_DEV float hpow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
 #endif
 // pow with the CONSTANT integer exponents the path uses -- Schlick's (1 - |c|)^5, the punctual lights' (d / cutoff)^4 -- as products: x^2 * x^2 (* x),

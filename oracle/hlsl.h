@@ -104,8 +104,70 @@ inline float3 reflect(float3 i, float3 n) { return i - 2 * dot(n, i) * n; }
 // on a scene that amplifies rounding.  The HIP path evaluates them the same way (pt_math.h pt_sincos).
 inline float o_sin(float x) { return (float)std::sin((double)x); }
 inline float o_cos(float x) { return (float)std::cos((double)x); }
+// atan2, log2, exp2, and pow / exp through them: DEFINED as float kernels (IEEE multiplies, adds, divisions in a fixed order; this file is
+// compiled without contraction), which the HIP path states operation for operation (csrc/pt_math.h co_atan2 / co_log2 / co_exp2): the same
+// bits on both sides.  HLSL leaves their precision open; these are within 1.3 / 2.9 / 1.2 ulp (tools/fit_transcendentals.py; checked
+// against libm in tests/test_oracle_kat.py).  The float routines of two libraries (glibc here, v_exp_f32 / v_log_f32 / ocml there) differ
+// in the last bit in several percent of their results, and double evaluation is slow on the GPU.
+inline uint32_t o_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+inline float o_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+inline float o_atan2(float y, float x) {
+    if (!(x == x) || !(y == y)) return NAN;
+    const float ax = fabsf(x), ay = fabsf(y), mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    float a;
+    if (mx == 0.0f) a = 0.0f;
+    else if (mx == INFINITY) a = mn == INFINITY ? 1.0f : 0.0f;
+    else a = mn / mx;
+    const float s = a * a;
+    float q = -0x1.40bebap-9f;
+    q = q * s + 0x1.c293dap-7f; q = q * s + -0x1.2920fep-5f; q = q * s + 0x1.0168bap-4f; q = q * s + -0x1.634104p-4f;
+    q = q * s + 0x1.c41dd4p-4f; q = q * s + -0x1.246facp-3f; q = q * s + 0x1.999860p-3f; q = q * s + -0x1.555554p-2f;
+    float r = a + a * (s * q);
+    if (ay > ax) r = 1.57079637f - r;
+    if (o_bits(x) >> 31) r = 3.14159274f - r;
+    return copysignf(r, y);
+}
+inline float o_log2(float x) {
+    if (!(x > 0.0f)) return x == 0.0f ? -INFINITY : NAN;
+    if (x == INFINITY) return x;
+    int e = 0;
+    if (x < 1.17549435e-38f) { x *= 16777216.0f; e = -24; }
+    const uint32_t b = o_bits(x);
+    e += (int)(b >> 23) - 127;
+    float m = o_float((b & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421354f) { m *= 0.5f; e += 1; }
+    const float t = (m - 1.0f) / (m + 1.0f), s = t * t;
+    float q = 0x1.ba1838p-2f;
+    q = q * s + 0x1.274720p-1f; q = q * s + 0x1.ec70e6p-1f; q = q * s + 0x1.715476p+1f;
+    return (float)e + t * q;
+}
+inline float o_exp2_reduced(float r) {                       // 2^r, r in [-1/2, 1/2]
+    float q = 0x1.444004p-13f;
+    q = q * r + 0x1.5f0896p-10f; q = q * r + 0x1.3b2a1cp-7f; q = q * r + 0x1.c6af6cp-5f; q = q * r + 0x1.ebfbe0p-3f; q = q * r + 0x1.62e430p-1f;
+    return 1.0f + r * q;
+}
+inline float o_scale2(float v, float n) {                       // v * 2^n, n an integer in [-125, 128]: two exact factors (2^128 is not a float)
+    const int k = (int)n, h = k / 2, g = k - h;
+    return v * o_float((uint32_t)(h + 127) << 23) * o_float((uint32_t)(g + 127) << 23);
+}
+inline float o_exp2(float p) {
+    if (!(p == p)) return p;
+    if (p >= 128.0f) return INFINITY;
+    if (p < -125.0f) return 0.0f;                            // results below the normal range are zero
+    const float n = rintf(p);
+    return o_scale2(o_exp2_reduced(p - n), n);                // (p - n is exact)
+}
+// e^x: n = round(x / ln 2), r = x - n ln 2 with ln 2 in two parts (the first has 11 trailing zero bits: n times it is exact), e^r = 2^(r / ln 2)
+inline float o_exp(float x) {
+    if (!(x == x)) return x;
+    if (x > 88.75f) return INFINITY;
+    if (x < -86.5f) return 0.0f;
+    const float n = rintf(x * 1.44269504f);
+    const float r = (x - n * 0.693145751953125f) - n * 1.42860677e-06f;
+    return o_scale2(o_exp2_reduced(r * 1.44269504f), n);
+}
 // pow(x,y) = exp2(y*log2(x)): x<0 -> NaN, pow(0, y>0) = 0.
-inline float hpow(float x, float y) { return exp2f(y * log2f(x)); }
+inline float hpow(float x, float y) { return o_exp2(y * o_log2(x)); }
 // pow with the constant integer exponents 5 (Schlick's Fresnel, Bsdf.hlsli:39-47) and 4 (the light falloff, Lights.hlsli:41) as correctly rounded
 // products, NaN for a negative base like the exp2 / log2 form: HLSL leaves pow's precision open (and shader compilers expand such pows); this is
 // the definition the HIP kernels evaluate to the same bits (csrc/pt_math.h hpow5 / hpow4) -- two approximate exp2 / log2 libraries are not.

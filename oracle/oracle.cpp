@@ -1136,7 +1136,7 @@ static void env_from_equirect(EnvMap& e, const float* rgb, int w, int h) {
     for (int f = 0; f < 6; f++) for (int y = 0; y < N; y++) for (int x = 0; x < N; x++) {
         float2 uv = PixelToUV({x, y}, {N, N});
         float3 d = CubemapToDirection(f, uv);                                   // same table as the shader's switch
-        float2 eq = {atan2f(d.y, d.x) / 6.28318530717f, 1 - ((d.z + 1) / 2)};   // equal-area in z (quirk q8)
+        float2 eq = {o_atan2(d.y, d.x) / 6.28318530717f, 1 - ((d.z + 1) / 2)};   // equal-area in z (quirk q8)
         float3 c = sample_equirect(rgb, w, h, eq);
         uint16_t* p = &e.cube[0][(((size_t)f * N + y) * N + x) * 4];
         p[0] = float_to_half(c.x); p[1] = float_to_half(c.y); p[2] = float_to_half(c.z); p[3] = float_to_half(1.0f);
@@ -1298,6 +1298,25 @@ void orc_env_read(void* h, int env, uint16_t* cube_rgba16f, float* pyramid) {
     EnvMap& e = ((Oracle*)h)->envs[env];
     if (cube_rgba16f) memcpy(cube_rgba16f, e.cube[0].data(), e.cube[0].size() * 2);
     if (pyramid) for (auto& l : e.imp) { memcpy(pyramid, l.data(), l.size() * 4); pyramid += l.size(); }
+}
+// the oracle's own math routines on arrays (same op numbers as the HIP library's pt_debug_math test hook)
+void orc_math(int op, const float* a, const float* b, float* out, int n) {
+    for (int i = 0; i < n; i++) {
+        const float x = a[i], y = b[i];
+        float r = 0;
+        switch (op) {
+            case 0: r = o_atan2(x, y); break;
+            case 1: r = hpow(x, y); break;
+            case 2: r = o_exp(x); break;
+            case 3: r = o_log2(x); break;
+            case 4: r = o_exp2(x); break;
+            case 5: r = o_sin(x); break;
+            case 6: r = o_cos(x); break;
+            case 7: r = x / y; break;
+            case 8: r = hpow5(x); break;
+        }
+        out[i] = r;
+    }
 }
 void orc_set_bounce_limit(void* h, int limit) { ((Oracle*)h)->bounce_limit = limit; }
 void orc_set_brute_force(void* h, int on) { ((Oracle*)h)->brute_force = on != 0; }

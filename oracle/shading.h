@@ -94,7 +94,7 @@ inline uint32_t EncodeTangentSpaceShader(float3 normal, float4 tangent) {
     float3 ct, cb;
     CreateBasisAccurate(normal, ct, cb);
     float3 t3 = {tangent.x, tangent.y, tangent.z};
-    float angle = atan2f(dot(t3, cb), dot(t3, ct));
+    float angle = o_atan2(dot(t3, cb), dot(t3, ct));
     float enc_t = (angle / TAU) + 0.5f;
     uint32_t qt = f2u(enc_t * 1023 + 0.5f);
     uint32_t qw = tangent.w == 1 ? 3u : 0u;
@@ -109,7 +109,7 @@ inline uint32_t EncodeTangentSpaceHost(float3 normal, float4 tangent) {
     float3 ct, cb;
     CreateBasisAccurate(normal, ct, cb);                           // Gltf.cpp:57-63 is the same basis
     float3 t3 = {tangent.x, tangent.y, tangent.z};
-    float angle = atan2f(dot(t3, cb), dot(t3, ct));
+    float angle = o_atan2(dot(t3, cb), dot(t3, ct));
     float enc_t = (angle / 6.283185307179586f) + 0.5f;
     uint32_t qt = f2u(clamp(enc_t, 0, 1) * 1023.0f + 0.5f);
     uint32_t qw = tangent.w == 1.0f ? 3u : 0u;
@@ -151,7 +151,7 @@ inline float3 SquareToSphere(float2 s) {                            // :124-136
 }
 inline float2 SphereToSquare(float3 p) {                            // :138-149
     float r = sqrtf(1 - fabsf(p.z));
-    float phi = atan2f(fabsf(p.y), fabsf(p.x));
+    float phi = o_atan2(fabsf(p.y), fabsf(p.x));
     float d = sign(p.z) * (1 - r);
     float diff = r * ((4 / PI) * phi - 1);
     return {sign(p.x) * 0.5f * (1 - d - diff), sign(p.y) * 0.5f * (1 - d + diff)};
@@ -274,8 +274,8 @@ inline float SheenL(float alpha, float x) {                         // :175-184
     return a / (1 + b * hpow(x, c)) + d * x + e;
 }
 inline float SheenShadowing(float alpha, float c) {                 // :186-193
-    if (c < 0.5f) return expf(SheenL(alpha, c));
-    return expf(2 * SheenL(alpha, 0.5f) - SheenL(alpha, 1 - c));
+    if (c < 0.5f) return o_exp(SheenL(alpha, c));
+    return o_exp(2 * SheenL(alpha, 0.5f) - SheenL(alpha, 1 - c));
 }
 inline float SheenVisibility(float alpha, float ndl, float ndv) {   // :195-198
     return clamp(1 / ((1 + SheenShadowing(alpha, ndl) + SheenShadowing(alpha, ndv)) * 4 * ndl * ndv), 0, 1);

@@ -45,3 +45,46 @@ def surface_rays(o, s, n, seed):
     second = np.zeros((m, 8), np.float32); second[:, 0:3] = origin; second[:, 4:7] = d
     second[:, 7] = np.where(rng.random(m) < 0.25, rng.random(m) * 0.5, 1000.0).astype(np.float32)
     return first, second
+
+
+MATH_OPS = {"atan2": 0, "pow": 1, "exp": 2, "log2": 3, "exp2": 4, "sin": 5, "cos": 6, "div": 7, "pow5": 8}
+
+
+def math_inputs(seed=3, n=400_000):
+    """Arguments for the co-defined math routines: wide random ranges plus every special value."""
+    rng = np.random.default_rng(seed)
+    special = np.float32([0.0, -0.0, 1.0, -1.0, 2.0, 0.5, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1.1754944e-38, 3.4028235e38, -3.4028235e38, 1e-30, 88.75, -86.5, 128.0, -125.0, 127.5, -124.5])
+    wide = lambda: (rng.standard_normal(n) * 10.0 ** rng.uniform(-8, 8, n)).astype(np.float32)
+    out = {}
+    sa, sb = np.meshgrid(special, special)
+    out["atan2"] = (np.concatenate([wide(), sa.ravel(), rng.standard_normal(n).astype(np.float32)]), np.concatenate([wide(), sb.ravel(), rng.standard_normal(n).astype(np.float32)]))
+    out["div"] = out["atan2"]
+    base = np.concatenate([rng.uniform(0, 1, n), 10.0 ** rng.uniform(-30, 30, n), sa.ravel()]).astype(np.float32)
+    expo = np.concatenate([rng.uniform(0, 60, n), rng.uniform(-4, 4, n), sb.ravel()]).astype(np.float32)
+    out["pow"] = (base, expo)
+    e = np.concatenate([rng.uniform(-100, 100, n), rng.uniform(-6, 1, n), special]).astype(np.float32)
+    out["exp"] = (e, e)
+    p = np.concatenate([rng.uniform(-140, 140, n), special]).astype(np.float32)
+    out["exp2"] = (p, p)
+    l = np.concatenate([np.abs(wide()), rng.uniform(0.5, 2, n).astype(np.float32), special]).astype(np.float32)
+    out["log2"] = (l, l)
+    t = np.concatenate([rng.uniform(-7, 7, n), wide(), special]).astype(np.float32)
+    out["sin"] = (t, t); out["cos"] = (t, t)
+    f = np.concatenate([rng.uniform(-0.5, 1.5, n), special]).astype(np.float32)
+    out["pow5"] = (f, f)
+    return out
+
+
+def oracle_math(lib, op, a, b):
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32); out = np.zeros_like(a)
+    lib.orc_math.restype = None
+    lib.orc_math(C.c_int(MATH_OPS[op]), a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_int(len(a)))
+    return out
+
+
+def gpu_math(lib, op, a, b):
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32); out = np.zeros_like(a)
+    lib.pt_debug_math.restype = C.c_int
+    rc = lib.pt_debug_math(C.c_int(MATH_OPS[op]), a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), C.c_uint32(len(a)))
+    assert rc == 0, rc
+    return out

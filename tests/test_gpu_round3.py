@@ -598,3 +598,41 @@ def test_traversal_finds_the_oracles_hit_for_every_ray(R, scene):
     g = gpu_intersect(r, second, RF_ACCEPT_FIRST, 1); c = o.intersect_many(second, dxr_flags(RF_ACCEPT_FIRST), 1)
     assert np.array_equal(g[:, 0], c[:, 0]), int((g[:, 0] != c[:, 0]).sum())
     r.close(); o.close()
+
+
+# ---- the math both sides define: bit for bit ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("op", ["atan2", "pow", "exp", "log2", "exp2", "sin", "cos", "pow5"])
+def test_defined_math_is_bit_identical_to_the_oracles(R, op):
+    """atan2, log2, exp2, exp, pow (float kernels stated identically on both sides), sin / cos (evaluated in double, rounded once) and the
+    integer powers, through pt_debug_math (the kernels' own routines on caller-supplied arguments): the same bits as the oracle's for
+    ~10^6 arguments over wide ranges and every special value -- NaN for NaN.  sin / cos go through two different double libraries: equal
+    but for the cases where the double results straddle a float rounding boundary (none expected in 10^6)."""
+    from oracle import pyoracle
+    from ray_hook import math_inputs, oracle_math, gpu_math
+    r = R()
+    a, b = math_inputs()[op]
+    g = gpu_math(r.L, op, a, b); c = oracle_math(pyoracle.lib(), op, a, b)
+    same = (g.view(np.uint32) == c.view(np.uint32)) | (np.isnan(g) & np.isnan(c))
+    bad = np.nonzero(~same)[0]
+    for k in bad[:8]: print("   %s(%r, %r): gpu %r oracle %r" % (op, a[k], b[k], g[k], c[k]))
+    allowed = 2 if op in ("sin", "cos") else 0
+    assert len(bad) <= allowed, "%d of %d differ" % (len(bad), len(a))
+    r.close()
+
+
+def test_shortened_division_is_the_ieee_quotient(R):
+    """fdiv (pt_math.h: the division every shading formula uses) against the oracle's `/` on 10^6 operand pairs with results in the normal
+    range and divisors below 2^126 (the reciprocal of a larger one is subnormal) -- bit for bit; outside that the documented behaviour, pt_math.h."""
+    from oracle import pyoracle
+    from ray_hook import math_inputs, oracle_math, gpu_math
+    r = R()
+    a, b = math_inputs()["div"]
+    with np.errstate(all="ignore"):
+        q = a.astype(np.float64) / b.astype(np.float64)
+    normal = np.isfinite(q) & (np.abs(q) > 1.2e-38) & (np.abs(q) < 3.4e38) & (np.abs(b) > 1.2e-38) & (np.abs(b) < 8.5e37) & (np.abs(a) > 1.2e-38) & np.isfinite(a) & np.isfinite(b)
+    g = gpu_math(r.L, "div", a, b); c = oracle_math(pyoracle.lib(), "div", a, b)
+    assert normal.sum() > 700_000
+    bad = np.nonzero(normal & (g.view(np.uint32) != c.view(np.uint32)))[0]
+    for k in bad[:16]: print("   %r / %r: gpu %r oracle %r" % (a[k], b[k], g[k], c[k]))
+    assert len(bad) == 0, len(bad)
+    r.close()

@@ -500,3 +500,37 @@ def test_tonemap_reference_points(oracle_lib):
         L.orc_tonemap_pixel(C.byref(cfg), rgb.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
         assert 0 <= out[0] <= 1.0 and out[0] >= prev and abs(out[0] - out[1]) < 1e-3
         prev = out[0]
+
+
+def test_defined_transcendentals_against_libm(oracle_lib):
+    """atan2, log2, exp2, exp and pow are DEFINED by the oracle (hlsl.h o_atan2 ...: float kernels the HIP path states operation for operation,
+    so that both sides produce the same bits); HLSL leaves their precision open.  Here: they are the functions they claim to be -- within a few
+    ulp of libm's double results over wide ranges, with the special values of the C functions."""
+    from ray_hook import math_inputs, oracle_math
+    L = oracle_lib.lib()
+    inp = math_inputs(n=200_000)
+
+    def ulps(got, want):
+        ok = np.isfinite(want) & (np.abs(want) > 1.2e-38) & (np.abs(want) < 3.4e38)
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        return float((np.abs(got[ok].astype(np.float64) - want[ok]) / np.spacing(np.abs(want[ok].astype(np.float32))).astype(np.float64)).max())
+
+    with np.errstate(all="ignore"):
+        y, x = inp["atan2"]; g = oracle_math(L, "atan2", y, x); w = np.arctan2(y.astype(np.float64), x.astype(np.float64))
+        assert ulps(g, w) < 2.5
+        assert np.array_equal(np.signbit(g[~np.isnan(g)]), np.signbit(w[~np.isnan(w)]))
+        a, _ = inp["log2"]; g = oracle_math(L, "log2", a, a); w = np.log2(a.astype(np.float64))
+        far = np.abs(a - 1) > 0.01
+        assert ulps(g[far], w[far]) < 3.5 and np.nanmax(np.abs(g[~far] - w[~far])) < 4e-9
+        assert np.array_equal(np.isinf(g), np.isinf(w)) and np.array_equal(np.isnan(g), np.isnan(w))
+        p, _ = inp["exp2"]; g = oracle_math(L, "exp2", p, p); w = 2.0 ** p.astype(np.float64)
+        inside = (p >= -125) & (p < 127.99)
+        assert ulps(g[inside], w[inside]) < 1.6 and np.all(g[p < -125] == 0) and np.all(np.isinf(g[p >= 128]))
+        e, _ = inp["exp"]; g = oracle_math(L, "exp", e, e); w = np.exp(e.astype(np.float64))
+        inside = (e >= -86.5) & (e <= 88.7)
+        assert ulps(g[inside], w[inside]) < 2.0 and np.all(g[e < -86.5] == 0) and np.all(np.isinf(g[e > 88.75]))
+        b, q = inp["pow"]; g = oracle_math(L, "pow", b, q); w = b.astype(np.float64) ** q.astype(np.float64)
+        ok = np.isfinite(w) & (w > 1e-30) & (w < 1e30) & (b > 0) & np.isfinite(b) & np.isfinite(q)
+        # pow = exp2(y * log2 x) in float: the error of log2 (3 ulp) times |y log2 x|, like the hardware instruction pair it stands for
+        assert float((np.abs(g[ok] - w[ok]) / w[ok] / np.maximum(1.0, np.abs(q[ok] * np.log2(b[ok].astype(np.float64))))).max()) < 6e-7
+        assert np.all(np.isnan(g[(b < 0)])) and np.all(g[(b == 0) & (q > 0)] == 0) and np.all(g[(b == 1) & np.isfinite(q)] == 1)
