@@ -165,8 +165,9 @@ PT_DEV void pt_sincos(float x, float& s, float& c) {
 // direction -> importance-map texel mapping of the environment pdf (a last bit picks the neighbouring texel once in ~10^6 lookups: a MIS
 // weight off by up to a percent), pow and exp in the sheen lobe (five pows and two exps per evaluation).  Through double (like sin / cos)
 // they cost 7.7 ms of a 22.6 ms launch (measured: ocml's double atan2, log2, exp2 are long).  These: atan2 nothing measurable; pow / exp
-// 0.8 ms on the Sponza-class scene, whose curtains (3 % of the hits) put a sheen lane into most waves of the shade stage -- v_log_f32 /
-// v_exp_f32 were 3 instructions per pow, this is ~45 (as real calls instead of inlined: 1.0 ms).  PT_CO_TRANSCENDENTALS / PT_CO_ATAN2 /
+// 0.45 ms on the Sponza-class scene, whose curtains (3 % of the hits) put a sheen lane into most waves of the shade stage -- v_log_f32 /
+// v_exp_f32 were 3 instructions per pow, this is ~70 (0.8 ms before the view-dependent half of the sheen lobe was hoisted out of the three
+// evaluations a hit makes, pt_shading.h prepare_sheen; as real calls instead of inlined code 1.0 ms).  PT_CO_TRANSCENDENTALS / PT_CO_ATAN2 /
 // PT_CO_POW = 0: the library routines (A/B).
 #ifndef PT_CO_TRANSCENDENTALS
 #define PT_CO_TRANSCENDENTALS 1

@@ -402,6 +402,7 @@ struct Surface {                       // live subset of SurfaceProperties (Bsdf
     vec3 spec_color; float spec_factor, clearcoat, cc_rough;
     vec3 cc_n, sheen_color; float sheen_a, transmissive;
     vec3 emissive_texel;                                  // RM_TRIO_EMISSIVE materials: the filtered emissive texel, fetched with the PBR footprint
+    float sheen_lh, sheen_sv;                             // SheenL(alpha, 1/2) and SheenShadowing(alpha, n.v): the same in every evaluation at this vertex (prepare_sheen)
 };
 struct MatHeader {                     // the 128-B head of RMat in registers (8 x dwordx4 issued together)
     uint32_t flags; int32_t alpha_mode; float metalness_factor, roughness_factor;
@@ -658,16 +659,26 @@ PT_DEV float sheen_l(float alpha, float x) {                                    
     float d = lerpf(-1.97760f, -1.27393f, t), e = lerpf(-4.32054f, -4.85967f, t);
     return fdiv(a, 1 + b * hpow(x, c)) + d * x + e;
 }
-PT_DEV float sheen_shadowing(float alpha, float c) {                                                           // :186-193
+// `l_half` = sheen_l(alpha, 0.5f)
+PT_DEV float sheen_shadowing(float alpha, float c, float l_half) {                                             // :186-193
     if (c < 0.5f) return pt_exp(sheen_l(alpha, c));
-    return pt_exp(2 * sheen_l(alpha, 0.5f) - sheen_l(alpha, 1 - c));
+    return pt_exp(2 * l_half - sheen_l(alpha, 1 - c));
 }
-PT_DEV float sheen_brdf(float alpha, float ndl, float ndv, float ndh) {                                        // :166-173,195-203
+PT_DEV float sheen_alpha(const Surface& s) { return clampf(s.sheen_a, 0.000001f, 1); }
+// The parts of SheenBrdf that do not depend on the light direction, once per vertex instead of once per evaluation (three a hit: the two
+// light samples and the sampled direction): SheenL(alpha, 1/2) and the view direction's shadowing term -- 2 to 4 of the lobe's 5 to 7 pows
+// and one of its two exps.  Pure functions of the same arguments: the same bits as evaluating them in place.
+PT_DEV void prepare_sheen(Surface& s, vec3 v) {
+    const float sa = sheen_alpha(s);
+    s.sheen_lh = sheen_l(sa, 0.5f);
+    s.sheen_sv = sheen_shadowing(sa, to_local(s.at, s.ab, s.n, v).z, s.sheen_lh);
+}
+PT_DEV float sheen_brdf(const Surface& s, float alpha, float ndl, float ndv, float ndh) {                      // :166-173,195-203
     float inv_r = fdiv(1.0f, alpha);
     float sin2h = 1 - ndh * ndh;
     float d = fdiv((2 + inv_r) * hpow(sin2h, inv_r * 0.5f), 2 * kPi);
     // SheenBrdf passes (n_dot_v, n_dot_l) into SheenVisibility(alpha, n_dot_l, n_dot_v): swapped names, same product
-    float vis = clampf(fdiv(1.0f, (1 + sheen_shadowing(alpha, ndv) + sheen_shadowing(alpha, ndl)) * 4 * ndv * ndl), 0, 1);
+    float vis = clampf(fdiv(1.0f, (1 + s.sheen_sv + sheen_shadowing(alpha, ndl, s.sheen_lh)) * 4 * ndv * ndl), 0, 1);
     return d * vis;
 }
 PT_DEV float sheen_e(const float* lut, float alpha, float cos_theta) {   // Bsdf.hlsli:204-208: bilinear, clamp, 16x16
@@ -715,7 +726,7 @@ PT_DEV vec3 gltf_bsdf(const float* lut, const Surface& s, vec3 v, vec3 l, int mo
     vec3 dielectric = (1 - s.spec_factor * max3(fr)) * diffuse + s.spec_factor * fr * v3(spec);
     vec3 metal = refl ? v3(spec) * schlick3(s.albedo, hdv) : v3(0);                // ConductorFresnel :146-149
     vec3 material = lerp3(dielectric, metal, s.metalness);
-    float sa = clampf(s.sheen_a, 0.000001f, 1);
+    float sa = sheen_alpha(s);
     float ms = max3(s.sheen_color);                                               // SheenMix :210-214
 #ifndef PT_SHEEN_SKIP
 #define PT_SHEEN_SKIP 1
@@ -732,7 +743,7 @@ PT_DEV vec3 gltf_bsdf(const float* lut, const Surface& s, vec3 v, vec3 l, int mo
         material = v3(layer) + material * 1.0f;
     } else {
 #ifndef PT_PROBE_BASE_ONLY
-        vec3 sheen = refl ? v3(saturate(ll.z) * sheen_brdf(sa, ll.z, vl.z, hl.z)) : v3(0);
+        vec3 sheen = refl ? v3(saturate(ll.z) * sheen_brdf(s, sa, ll.z, vl.z, hl.z)) : v3(0);
 #else      // PROBE ONLY (tools/build_variant.sh): what the extension lobes cost a hit that has none; wrong for materials that do
         vec3 sheen = v3(0);
 #endif

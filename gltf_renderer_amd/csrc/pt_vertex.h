@@ -126,6 +126,8 @@ PT_DEV bool shade_closest_hit(const SceneRec& sc, const FrameConstants& fc, uint
         return true;
     }
     const Lobes lobes = lobe_probabilities(sp, view);
+    sp.sheen_lh = sp.sheen_sv = 0.0f;
+    if (!PT_SHEEN_SKIP || __any(sp.sheen_color.x != 0.0f || sp.sheen_color.y != 0.0f || sp.sheen_color.z != 0.0f)) prepare_sheen(sp, view);   // (gltf_bsdf's own condition)
     vec3 c = emissive_of(sc, mat, mh, va.tc, taps, sp.emissive_texel);                                                     // :925-926
     fu.origin_above = o_above;
     PT_TICK(2)
