@@ -152,7 +152,7 @@ __device__ __forceinline__ vec3 agx_tonemap(vec3 c) {                      // :4
                 0.137318972929847f * c.x + 0.761241990602591f * c.y + 0.101439036467562f * c.z,
                 0.11189821299995f * c.x + 0.0767994186031903f * c.y + 0.811302368396859f * c.z);
     const float log_min = -12.47393f, log_max = 4.026069f;
-    i = v3(clampf(log2f(i.x), log_min, log_max), clampf(log2f(i.y), log_min, log_max), clampf(log2f(i.z), log_min, log_max));
+    i = v3(clampf(co_log2(i.x), log_min, log_max), clampf(co_log2(i.y), log_min, log_max), clampf(co_log2(i.z), log_min, log_max));
     i = (i - log_min) / (log_max - log_min);
     i = agx_curve(i);
     vec3 o = v3(1.12710058f * i.x + -0.11060664f * i.y + -0.01649394f * i.z, -0.14132976f * i.x + 1.1578237f * i.y + -0.01649394f * i.z,

@@ -1223,7 +1223,7 @@ static float3 AgxTonemap(float3 c) {                                            
                                         {0.0482516061458583f, 0.101439036467562f, 0.811302368396859f}));
     c = mul(inset, c);
     const float log_min = -12.47393f, log_max = 4.026069f;
-    c = clamp(float3{log2f(c.x), log2f(c.y), log2f(c.z)}, log_min, log_max);
+    c = clamp(float3{o_log2(c.x), o_log2(c.y), o_log2(c.z)}, log_min, log_max);
     c = (c - log_min) / (log_max - log_min);
     c = AgxCurve(c);
     const float3x3 outset = transpose(M3({1.12710058f, -0.14132976f, -0.14132976f}, {-0.11060664f, 1.1578237f, -0.11060664f},

@@ -33,6 +33,8 @@ for f in range(N):
         A = r.readback(og)[..., :3].astype(np.float64); B = b[..., :3].astype(np.float64)
         rel = np.abs(A - B).max(axis=2) / np.maximum(np.abs(B).max(axis=2), 1e-4)
         sg = r.stats(); oracle_rays += o.counters()["rays"]
-        print("  %3d samples: tone-mapped rel L2 %.3e (contract 1e-3); pixels beyond 1e-3 / 1e-2 of the oracle's radiance: %d / %d of %d; rays GPU %d, oracle %d (%s); %.0f s"
-              % (f + 1, e, int((rel > 1e-3).sum()), int((rel > 1e-2).sum()), rel.size, sg.rays, oracle_rays, "equal" if sg.rays == oracle_rays else "DIFFERENT by %d" % (sg.rays - oracle_rays), time.time() - t0), flush=True)
+        rad_bits = int((r.readback(og)[..., :3].view(np.uint32) != b[..., :3].view(np.uint32)).any(axis=2).sum())
+        tm_bits = int((ta.view(np.uint32) != tb.view(np.uint32)).any(axis=2).sum())
+        print("  %3d samples: tone-mapped rel L2 %.3e (contract 1e-3); pixels beyond 1e-3 / 1e-2 of the oracle's radiance: %d / %d of %d; pixels not bit-identical: radiance %d, tone-mapped %d; rays GPU %d, oracle %d (%s); %.0f s"
+              % (f + 1, e, int((rel > 1e-3).sum()), int((rel > 1e-2).sum()), rel.size, rad_bits, tm_bits, sg.rays, oracle_rays, "equal" if sg.rays == oracle_rays else "DIFFERENT by %d" % (sg.rays - oracle_rays), time.time() - t0), flush=True)
 r.close(); o.close()
