@@ -397,6 +397,13 @@ public:
                 if ((long long)batch > room) batch = (int)room;
             }
             fc.cull_null_shadow = ctx->cull_null_shadow ? 1u : 0u;
+            {   // a sheen material among at most a tenth of the materials: its hits are shaded together (the default; MIPT_DEFER_RARE=0 / 1 forces it)
+                size_t rare = 0;
+                for (const RMat& m : ctx->rmats_host) rare += (m.sheen_color_factor[0] != 0.0f || m.sheen_color_factor[1] != 0.0f || m.sheen_color_factor[2] != 0.0f) ? 1 : 0;
+                fc.defer_rare = (rare != 0 && rare * 10 <= ctx->rmats_host.size()) ? 1u : 0u;
+                static const int forced = [] { const char* e = getenv("MIPT_DEFER_RARE"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+                if (forced >= 0) fc.defer_rare = (uint32_t)forced;
+            }
             fc.spp = 1; fc.pixel_slots = fc.my_tiles * 256u;
             fc.div_pixel_slots = FastDiv::make(fc.pixel_slots); fc.div_tiles_x = FastDiv::make(fc.tiles_x);
             fc.seed_step = settings->use_frame_as_seed ? 1u : 0u;
@@ -888,6 +895,15 @@ extern "C" int pt_debug_intersect(pt_ctx* ctx, const float* rays, uint32_t n, ui
     }
     hipError_t e = hipMemcpyAsync(d_rays, rays, (size_t)n * 32, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) { launch_debug_intersect(sc, d_rays, n, ray_flags, mode, d_out, ctx->stream); e = hipGetLastError(); }
+    if (e == hipSuccess && getenv("MIPT_DEBUG_INTERSECT_TIMING")) {           // probe (tools/ray_order_probe.py): the same launch timed, 5 repeats
+        hipEvent_t ev[2]; hipEventCreate(&ev[0]); hipEventCreate(&ev[1]);
+        hipEventRecord(ev[0], ctx->stream);
+        for (int k = 0; k < 5; k++) launch_debug_intersect(sc, d_rays, n, ray_flags, mode, d_out, ctx->stream);
+        hipEventRecord(ev[1], ctx->stream); hipEventSynchronize(ev[1]);
+        float ms = 0; hipEventElapsedTime(&ms, ev[0], ev[1]);
+        fprintf(stderr, "pt_debug_intersect: %u rays, %.3f ms per launch, %.1f Mrays/s\n", n, ms / 5, n / (ms / 5) * 1e-3);
+        hipEventDestroy(ev[0]); hipEventDestroy(ev[1]);
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     return done(e == hipSuccess ? PT_OK : PT_ERR_DEVICE, std::string("pt_debug_intersect: ") + hipGetErrorString(e));

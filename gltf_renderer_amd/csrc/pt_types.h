@@ -237,6 +237,8 @@ struct FrameConstants {
     // `spp` consecutive PathtraceScene calls: sample k uses seed + k * seed_step and blends with accumulated_frames + k.
     uint32_t spp, pixel_slots, seed_step;
     uint32_t cull_null_shadow;       // pt_set_null_shadow_culling: do not trace a shadow ray whose pending term is exactly zero
+    uint32_t defer_rare;             // the shade stage sets hits on rare materials aside and shades them together (k_wf_shade; set by the host
+                                     // when a FEW of the scene's materials have the feature: with none there is nothing to gain, with many nothing either)
     FastDiv div_pixel_slots, div_tiles_x;   // divisions by pixel_slots / tiles_x (slot_pixel, slot_sample)
 };
 

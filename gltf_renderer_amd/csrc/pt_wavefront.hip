@@ -485,6 +485,36 @@ PT_DEV void apply_pending(const WfBuffers& wf, uint32_t slot, uint32_t pf, vec3&
     if ((pf & 2u) && pl.w > 0.0f) L += v3(pl.x, pl.y, pl.z) * pl.w;
 }
 
+// Material features whose hits the shade stage sets aside and shades together (k_wf_shade): 1 sheen, 2 clearcoat, 4 transmission, 8 anisotropy;
+// 0 (the default): none, the code is not compiled in.  MEASURED with 1 (sheen) on the bench scene, where 3 % of the hits put a sheen lane into
+// nearly every wave: shade stage 9.06 -> 8.80 ms per 8-sample launch (+1 % rays/s), but a single-sample launch 4.00 -> 4.05 ms (a wave rarely
+// collects enough notes before its queue ends, and the last iteration over the few it has is an iteration more), the material grid -1 %
+// (a sixth of its hits are sheen: the extra iterations cost more than the shared code saves) and a scene without sheen -0.8 % (the test
+// itself).  The noted hits cost a full iteration per 60 while the lanes they left idle shorten nothing, which eats most of what the
+// shared lobe code saves.  Enabled per scene by the host (FrameConstants::defer_rare) when compiled in.  profiles/EXPERIMENTS.md.
+#ifndef PT_DEFER_FEATURES
+#define PT_DEFER_FEATURES 0
+#endif
+#ifndef PT_DEFER_FLUSH
+#define PT_DEFER_FLUSH 60
+#endif
+#ifndef PT_DEFER_MAJORITY
+#define PT_DEFER_MAJORITY 4
+#endif
+constexpr uint32_t kNoHeld = 0xffffffffu;
+constexpr int kDeferFlush = PT_DEFER_FLUSH;        // notes in a wave that trigger the iteration over them
+constexpr uint32_t kDeferMajority = PT_DEFER_MAJORITY; // a chunk with this many rare hits is shaded in place
+PT_DEV bool material_is_rare(const SceneRec& sc, uint32_t inst_id) {
+    const ShadeInst inst = load_shade_inst(sc, inst_id);
+    const MatHeader mh = material_header(sc, inst.material_id);
+    bool rare = false;
+    if (PT_DEFER_FEATURES & 1) rare = rare || mh.sheen_color_factor.x != 0.0f || mh.sheen_color_factor.y != 0.0f || mh.sheen_color_factor.z != 0.0f;
+    if (PT_DEFER_FEATURES & 2) rare = rare || mh.clearcoat_factor != 0.0f;
+    if (PT_DEFER_FEATURES & 4) rare = rare || mh.transmission_factor != 0.0f;
+    if (PT_DEFER_FEATURES & 8) rare = rare || mh.anisotropy_strength != 0.0f;
+    return rare;
+}
+
 #ifndef PT_SHADE_DYNAMIC
 #define PT_SHADE_DYNAMIC 1    // shade-stage waves pull 64-entry chunks from the shard's head counter (0: static rounds over the grid's stride)
 #endif
@@ -525,12 +555,29 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
     uint32_t chunk = 0;
     if (lane64 == 0) chunk = atomicAdd(shade_head, 64u);
     chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
-    while (chunk < n) {
+    // Hits on RARE materials (PT_DEFER_FEATURES: sheen, ...) are set aside and shaded together.  A wave executes a lobe's code if ONE of its
+    // lanes needs it, and 3 % of the bench scene's hits (its curtains) put a sheen lane into nearly every wave: the lobe's ~600 instructions
+    // a hit ran in almost every wave with two or three lanes active.  Instead, a lane that meets a rare hit only notes the queue entry
+    // (`held`: one note per lane, handed to any free lane of the wave through LDS so that the notes pack densely) and does not shade it;
+    // once most lanes hold a note -- or the queue is empty -- the wave shades the noted entries in one iteration, all lanes in the rare
+    // code together.  Only the order of the follow-up queues changes: images are bit-identical (tools/compare_builds.py).
+    const bool defer_on = PT_DEFER_FEATURES != 0 && fc.defer_rare != 0;
+    uint32_t held = kNoHeld;
+    __shared__ uint32_t s_hand[kBlock];                              // the hand-over slots, 64 per wave
+    uint32_t* hand = s_hand + (threadIdx.x & ~63u);
+    for (;;) {
+        const bool more = chunk < n;
+        const unsigned long long held_mask = __ballot(held != kNoHeld);
+        if (!more && held_mask == 0) break;
+        const bool flush = defer_on && (!more || __popcll(held_mask) >= kDeferFlush);       // (wave-uniform)
         uint32_t next_chunk = 0;
-        if (lane64 == 0) next_chunk = atomicAdd(shade_head, 64u);
-        const uint32_t i = chunk + lane64;
-        const bool active = i < n;
+        if (!flush && lane64 == 0) next_chunk = atomicAdd(shade_head, 64u);
+        const uint32_t i = flush ? held : chunk + lane64;
+        const bool active = flush ? held != kNoHeld : i < n;
+        if (flush) held = kNoHeld;
 #else
+    const bool flush = true;                                          // (no setting aside in this mode)
+    const unsigned long long held_mask = 0; uint32_t held = kNoHeld; uint32_t* hand = nullptr; const uint32_t lane64 = threadIdx.x & 63u;
     const uint32_t rounds = (n + sv.stride - 1) / sv.stride;      // uniform per workgroup: ballots inside stay wave-uniform
     for (uint32_t rnd = 0; rnd < rounds; rnd++) {
         const uint32_t i = rnd * sv.stride + sv.member * kBlock + threadIdx.x;
@@ -543,44 +590,79 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
         uint32_t slot = 0;
         PathState ps;
         ps.beta = v3(0); ps.thr = v3(0); ps.prev_pdf = 0; ps.rc = 0; ps.bounce = 0; ps.prev_mis = false;
+        // ---- 1. everything the entry needs, fetched in one round trip
+        float4 o = make_float4(0, 0, 0, 0), d = o, h = o, bp = o, tm = o, Lq = o, pe = o, pl = o;
+        uint32_t hb = kMissTri;
+        const ShadePacket* packet_at = sc.shade;
+        RawPacket packet;
+#if PT_ENV_PREPASS
+        EnvSample es;
+        es.dir = v3(0, 0, 1); es.pdf = 1; es.color = v3(0);
+#endif
+        const bool with_state = !(PT_FIRST_VERTEX_STATELESS && bounce == 0);          // (wave-uniform: `bounce` is a kernel argument)
         if (active) {
-            const float4 o = QLD(wf.ray_o[cur][base + i]), d = QLD(wf.ray_d[cur][base + i]), h = QLD(wf.hit[base + i]);
+            o = QLD(wf.ray_o[cur][base + i]); d = QLD(wf.ray_d[cur][base + i]); h = QLD(wf.hit[base + i]);
 #if PT_ENV_PREPASS
             // the vertex's environment light sample, drawn by the traversal stage (env_prepass); without an environment the sample is
             // the constant the in-place code produces.  Fetched with the entry whether or not this vertex will use it: no extra round trip.
-            EnvSample es;
-            es.dir = v3(0, 0, 1); es.pdf = 1; es.color = v3(0);
             if (env_prepass_wanted(sc, fc, bounce)) {
                 const float4 ea = QLD(wf.env_a[base + i]), eb = QLD(wf.env_b[base + i]);
                 es.dir = v3(ea.x, ea.y, ea.z); es.pdf = ea.w; es.color = v3(eb.x, eb.y, eb.z);
             }
 #endif
             slot = __float_as_uint(d.w);
+            // the hit's shading packet depends on the queue entry only, like the path state below: one round trip for both
+            hb = __float_as_uint(h.w);
+#ifdef PT_PROBE_NO_PACKET     // PROBE ONLY: every hit reads one of 64 packets -- wrong geometry, what the shading-packet gathers cost
+            packet_at = sc.shade + (hb == kMissTri ? 0u : (hb & 63u));
+#else
+            packet_at = sc.shade + (hb == kMissTri ? 0u : (hb & 0x7fffffffu));
+#endif
+            packet = load_shade_packet_raw(packet_at);
+            if (with_state) {
+#if PT_BT_IN_QUEUE
+                bp = QLD(wf.q_beta[cur][base + i]); tm = QLD(wf.q_thr[cur][base + i]);
+#else
+                bp = SLD(wf.beta_pdf[SIDX(slot)]); tm = SLD(wf.thr_misc[SIDX(slot)]);
+#endif
+#ifndef PT_PROBE_NO_LP        // PROBE ONLY: the radiance and pending-term records are neither read nor written -- black image, same paths: what that class of state costs
+                Lq = SLD(wf.L[SIDX(slot)]); pe = SLD(PEND_ENV(slot)); pl = SLD(PEND_LIGHT(slot));
+#endif
+            }
+        }
+        // ---- 2. rare hits are set aside (wave-uniform control flow)
+        bool set_aside = false;
+#if PT_SHADE_DYNAMIC
+        if (defer_on && !flush) {
+            const bool rare = active && hb != kMissTri && material_is_rare(sc, raw_packet_inst(packet));
+            const unsigned long long R = __ballot(rare), F = ~held_mask;
+            const uint32_t nR = (uint32_t)__popcll(R), nF = (uint32_t)__popcll(F);
+            if (nR != 0 && nR < kDeferMajority) {                 // (a chunk made mostly of rare hits is shaded as it is: nothing to gain)
+                const unsigned long long below = (1ull << lane64) - 1ull;
+                const uint32_t rr = (uint32_t)__popcll(R & below), rf = (uint32_t)__popcll(F & below);
+                if (rare && rr < nF) { hand[rr] = i; set_aside = true; }       // the k-th rare lane's note goes to the k-th free lane
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (held == kNoHeld && rf < min(nR, nF)) held = hand[rf];
+            }
+        }
+#endif
+        // ---- 3. shade
+        if (active && !set_aside) {
             Ray ray;
             ray.o = v3(o.x, o.y, o.z); ray.tmin = 0; ray.d = v3(d.x, d.y, d.z); ray.tmax = o.w;
-            // the hit's shading packet depends on the queue entry only, like the path state below: one round trip for both
-            const uint32_t hb = __float_as_uint(h.w);
-#ifdef PT_PROBE_NO_PACKET     // PROBE ONLY: every hit reads one of 64 packets -- wrong geometry, what the shading-packet gathers cost
-            const ShadePacket* packet_at = sc.shade + (hb == kMissTri ? 0u : (hb & 63u));
-#else
-            const ShadePacket* packet_at = sc.shade + (hb == kMissTri ? 0u : (hb & 0x7fffffffu));
-#endif
-            const RawPacket packet = load_shade_packet_raw(packet_at);
             vec3 L = v3(0);
             ps.beta = v3(1); ps.prev_pdf = 0; ps.thr = v3(1); ps.rc = kRcAfterCamera; ps.bounce = 0; ps.prev_mis = false;      // a path at its first vertex
-            if (!(PT_FIRST_VERTEX_STATELESS && bounce == 0)) {                  // (wave-uniform: `bounce` is a kernel argument)
-#if PT_BT_IN_QUEUE
-                const float4 bp = QLD(wf.q_beta[cur][base + i]), tm = QLD(wf.q_thr[cur][base + i]);
-#else
-                const float4 bp = SLD(wf.beta_pdf[SIDX(slot)]), tm = SLD(wf.thr_misc[SIDX(slot)]);
-#endif
+            if (with_state) {
                 const uint32_t misc = __float_as_uint(tm.w);
                 ps.beta = v3(bp.x, bp.y, bp.z); ps.prev_pdf = bp.w; ps.thr = v3(tm.x, tm.y, tm.z);
                 ps.rc = (int)(misc & 0xffffu); ps.bounce = (int)((misc >> 16) & 0x7fffu); ps.prev_mis = (misc >> 31) != 0;
-#ifndef PT_PROBE_NO_LP        // PROBE ONLY: the radiance and pending-term records are neither read nor written -- black image, same paths: what that class of state costs
-                const float4 Lq = SLD(wf.L[SIDX(slot)]);
+#ifndef PT_PROBE_NO_LP
                 L = v3(Lq.x, Lq.y, Lq.z);
-                apply_pending(wf, slot, __float_as_uint(Lq.w), L);
+                const uint32_t pfb = __float_as_uint(Lq.w);                      // the pending bits that travel in L.w
+                if ((pfb & 1u) && pe.w > 0.0f) L += v3(pe.x, pe.y, pe.z) * pe.w;
+                if ((pfb & 2u) && pl.w > 0.0f) L += v3(pl.x, pl.y, pl.z) * pl.w;
 #endif
             }
             uint32_t pf = 0;
@@ -660,7 +742,7 @@ __global__ __launch_bounds__(kBlock, PT_SHADE_WAVES) void k_wf_shade(SceneRec sc
             n_bounce++;
         }
 #if PT_SHADE_DYNAMIC
-        chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_chunk);
+        if (!flush) chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_chunk);
 #endif
     }
     flush_counters(counters, threadIdx.x & 63, 0, n_bounce, n_shadow, n_hits, st);

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Run ON THE GPU BOX: kernel trace of single-sample launches (bench.py --spp 1): per-launch kernel durations in launch order and the
-# gaps between them, for the reference-semantics figure (one 1-spp pt_trace).   usage: tools/trace_1spp.sh [tag]
+# gaps between them, for the reference-semantics figure (one 1-spp pt_trace).   usage: tools/trace_1spp.sh [tag] [spp]
 set -o pipefail
-TAG=${1:-1spp}; OUT=gpurun_out/trace_$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python3 bench.py --spp 1 --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/bench.log 2>&1 || { tail -5 $OUT/bench.log; exit 1; }
+SPP=${2:-1}; TAG=${1:-1spp}; OUT=gpurun_out/trace_$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python3 bench.py --spp $SPP --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/bench.log 2>&1 || { tail -5 $OUT/bench.log; exit 1; }
 python3 - <<PY
 import csv, glob
 rows = []
