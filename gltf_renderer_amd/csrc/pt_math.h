@@ -149,6 +149,9 @@ PT_DEV float pt_cos(float x) { return cosf(x); }
 #define PT_SINCOS_PAIR 1
 #endif
 PT_DEV void pt_sincos(float x, float& s, float& c) {
+#ifdef PT_PROBE_FAST_SINCOS      // PROBE ONLY: the hardware's approximate v_sin_f32 / v_cos_f32 -- what an ideal sincos would save
+    s = __sinf(x); c = __cosf(x); return;
+#endif
 #if PT_F64_TRANSCENDENTALS && PT_SINCOS_PAIR
     double ds, dc;
     sincos((double)x, &ds, &dc);
