@@ -299,7 +299,7 @@ PT_DEV bool candidate_stands(const Trav& t, const SceneRec& sc, vec3 v0, vec3 e1
     }
     if (tt < limit) return true;
     if (!(PT_TIE_BREAK && t.mode == 0 && t.best.tri >= 0)) return false;                // tt == limit: the interval's end, or a tie with the hit held
-    const uint4 h0 = *(const uint4*)((const float4*)sc.tris + (size_t)t.best.tri * 3), h1 = *(const uint4*)((const float4*)sc.tris + (size_t)t.best.tri * 3 + 1);
+    const uint4 h0 = *(const uint4*)((const float4*)sc.tris + (size_t)t.best.tri * kTriFloat4), h1 = *(const uint4*)((const float4*)sc.tris + (size_t)t.best.tri * kTriFloat4 + 1);
     return inst < h0.w || (inst == h0.w && prim < h1.w);
 }
 
@@ -318,7 +318,7 @@ PT_DEV void trav_leaf_step(Trav& t, const SceneRec& sc, const int* lds_stack, co
 #endif
   for (int k = 0; k < n_here && !stop; k++) {
     const int tri = first + k;
-    const float4* tp = (const float4*)sc.tris + (size_t)tri * 3;
+    const float4* tp = (const float4*)sc.tris + (size_t)tri * kTriFloat4;
     float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
     if (COUNT) st.tris++;
     vec3 v0 = v3(q0.x, q0.y, q0.z), e1 = v3(q1.x, q1.y, q1.z), e2 = v3(q2.x, q2.y, q2.z);
