@@ -127,12 +127,12 @@ PT_DEV vec3 lerp3(vec3 a, vec3 b, float t) { return a + t * (b - a); }
 PT_DEV float signf(float x) { return x > 0 ? 1.0f : (x < 0 ? -1.0f : 0.0f); }
 PT_DEV vec3 reflect(vec3 i, vec3 n) { return i - 2 * dot(n, i) * n; }
 // sin and cos are evaluated in DOUBLE precision and rounded once: the correctly rounded fp32 value in all but one case in ~1e9, which is
-// what the CPU oracle's libm returns.  The device library's fp32 sinf / cosf are within 1-2 ulp of that -- and on the Sponza-class scene
-// those last bits, in the directions the BSDF samplers and the environment sampler draw, were ALL that still made 0.04 % of the
-// pixel-samples take another path than the oracle's: with them the scene measures 8.4e-4 at 64 spp (4.9e-3 without) and no pixel-sample
-// beyond 1e-2.  Costs ~1 % of the frame rate (a few calls per hit; MI355X runs fp64 at half the fp32 rate).  atan2 and exp feed continuous
-// quantities only (a pdf on a miss, the sheen visibility): their fp32 library versions leave every parity figure where it is, their
-// double versions cost another 0.5 %, so they stay fp32; pow through double costs 17 % and changes nothing.
+// what the CPU oracle computes the same way (its libm's double sin / cos; tests/test_gpu_round3.py: bit-identical on 10^6 arguments).  The
+// device library's fp32 sinf / cosf are within 1-2 ulp of that -- and on the Sponza-class scene those last bits, in the directions the BSDF
+// samplers and the environment sampler draw, made 0.04 % of the pixel-samples take another path than the oracle's (round 2: 8.4e-4 at
+// 64 spp with them, 4.9e-3 without).  The cost is not measurable: the hardware's approximate v_sin_f32 / v_cos_f32 in their place
+// (PT_PROBE_FAST_SINCOS, wrong images) save 0.05 ms of a 23-ms launch -- two calls a hit.  The other transcendentals (atan2, log2, exp2,
+// exp, pow) are float kernels defined below: through double THEY are expensive (7.7 ms a launch).
 // PT_F64_TRANSCENDENTALS=0: the fp32 library sinf / cosf (A/B).
 #ifndef PT_F64_TRANSCENDENTALS
 #define PT_F64_TRANSCENDENTALS 1
