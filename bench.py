@@ -306,8 +306,9 @@ def main():
                        "rays_per_frame": round(rays_total / args.steps / spp, 1), "bvh_build_ms": round(accel_ms, 3),
                        "bvh_stack_need": int(st_build.bvh_stack_need), "scene_setup_s": round(t_setup, 1)},
         }
+        # N = 1 is the first point of either series; it carries the mode of the series the N > 1 lines of the same command report
+        result["scaling"] = "weak" if (args.headline == "weak" and not args.animate) else "strong"
         if world > 1:
-            result["scaling"] = "weak" if headline_weak else "strong"          # N = 1 has no scaling mode: the key is omitted there
             result["config"]["scaling_note"] = ("weak: per-GPU work fixed -- every rank renders its 1/%d of the tiles with %d samples per step (8 per GPU); "
                                                 "strong_scaling = the 8-spp step split %d ways" % (world, spp, world)) if headline_weak else \
                                                ("strong: the %d-spp step split %d ways; weak_scaling = %d samples per step" % (spp, world, weak_spp))
