@@ -708,7 +708,7 @@ def test_random_materials_and_lights_match_the_oracle_sample_for_sample(R, oracl
     """Twenty-five random material tables (every factor redrawn, each of the 15 texture slots bound or not with a random texture, sampler
     mode, UV set and KHR_texture_transform; alpha modes, double-sidedness) and light sets (types, ranges, cone angles incl. inner = outer) on the
     test scene's eleven mesh kinds, three single-sample frames each: no pixel-sample beyond 1e-3 of the oracle's, equal ray counts.
-    (tools/material_fuzz.py 3000 17 is the long version: 187 M pixel-samples, none beyond 1e-3, profiles/r03_flag_sweep.txt.)"""
+    (tools/material_fuzz.py 3000 17 is the long version: 187 M pixel-samples, none beyond 1e-3, profiles/r03_random_sweeps.txt.)"""
     import importlib.util, os
     spec = importlib.util.spec_from_file_location("material_fuzz", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "material_fuzz.py"))
     mf = importlib.util.module_from_spec(spec); spec.loader.exec_module(mf)
@@ -732,3 +732,28 @@ def test_random_materials_and_lights_match_the_oracle_sample_for_sample(R, oracl
             assert (rel > 1e-3).sum() == 0, (t, frame, int((rel > 1e-3).sum()), float(rel.max()))
             assert r.stats().rays == o.counters()["rays"], (t, frame)
         r.close(); o.close()
+
+
+def test_random_triangle_soups_traversal_equals_the_oracles_ray_for_ray(R, oracle_lib):
+    """Fifteen random scenes of 1-4 instances (rotated, non-uniformly scaled, mirrored, up to 1e4 from the coordinate origin) of random triangle
+    soups with degenerate triangles, exact duplicates (equal-distance ties) and axis-aligned sheets (boxes without thickness), each built with
+    one of the three builders: ~30 k rays each (between random points, along the axes, from points ON triangles, short intervals with tmin > 0)
+    through pt_debug_intersect and the oracle -- the same triangle, t, u, v and facing to the bit, with and without culling; the same occlusion
+    answer.  (tools/geometry_fuzz.py 1000 19 is the long version: 158 M ray queries in 1000 scenes, none different.)"""
+    import importlib.util, os
+    from ray_hook import gpu_intersect, dxr_flags, RF_CULL_BACK, RF_CULL_FRONT, RF_ACCEPT_FIRST
+    spec = importlib.util.spec_from_file_location("geometry_fuzz", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "geometry_fuzz.py"))
+    gf = importlib.util.module_from_spec(spec); spec.loader.exec_module(gf)
+    rng = np.random.default_rng(29); hits = 0.0
+    for t in range(15):
+        s = gf.random_scene(rng)
+        r = R(); s.upload(r); r.set_accel_builder(t % 3)
+        o = oracle_lib.Oracle(); s.upload(o)
+        rays = gf.random_rays(rng, o, gf.world_triangles(s), 12000)
+        for flags, mode in ((0, 0), (RF_CULL_BACK, 0), (RF_CULL_FRONT, 0), (RF_ACCEPT_FIRST, 1)):
+            g = gpu_intersect(r, rays, flags, mode); c = o.intersect_many(rays, dxr_flags(flags), mode)
+            if mode == 1: assert np.array_equal(g[:, 0], c[:, 0]), (t, flags)
+            else: assert np.array_equal(g[:, :7].view(np.uint32), c[:, :7].view(np.uint32)), (t, flags, int((g[:, :7].view(np.uint32) != c[:, :7].view(np.uint32)).any(axis=1).sum()))
+        hits += float(c[:, 0].mean())
+        r.close(); o.close()
+    assert hits / 15 > 0.2
