@@ -3,7 +3,7 @@
 BLEND quads), GPU against the oracle pixel-sample by pixel-sample.  Every material's factors are redrawn (metalness, roughness, ior, specular,
 clearcoat, anisotropy strength / rotation, sheen, transmission, emissive, alpha mode / cutoff, double-sidedness), each of the 15 texture slots is
 bound or not with a random texture, sampler (wrap / mirror / clamp, point / linear), UV set and KHR_texture_transform; lights get random types,
-positions, ranges and cone angles.   usage: python tools/material_fuzz.py [trials] [seed]"""
+positions, ranges and cone angles; the camera a random orbit pose and field of view (orthographic a quarter of the time).   usage: python tools/material_fuzz.py [trials] [seed]"""
 import math, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -40,6 +40,10 @@ def randomize(s, rng):
                 ts.offset[:] = (0, 0) if rng.random() < 0.5 else (u(-2, 2), u(-2, 2)); ts.scale[:] = (1, 1) if rng.random() < 0.5 else (u(-3, 3), u(0.1, 4))
             else:
                 ts.descriptor = -1
+    # the camera: any orbit pose around the scene, any field of view; orthographic a quarter of the time
+    from gltf_renderer_amd import camera
+    s.world_to_view = camera.orbit_world_to_view((u(-0.5, 0.5), u(-0.5, 0.5), u(0.2, 1.0)), u(1.5, 6.0), u(-3.2, 3.2), u(-0.3, 1.3))
+    s.y_fov = u(0.3, 2.6); s.ortho = (u(0.2, 1.0), u(0.2, 1.0)) if rng.random() < 0.25 else None
     for l in s.lights:
         l.type = int(rng.choice([abi.LIGHT_POINT, abi.LIGHT_SPOT, abi.LIGHT_DIRECTIONAL]))
         l.position[:] = (u(-3, 3), u(-3, 3), u(0.2, 4)); d = rng.standard_normal(3); l.direction[:] = d / np.linalg.norm(d)
