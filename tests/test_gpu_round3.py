@@ -783,3 +783,23 @@ def test_random_poses_and_morph_sets_skin_to_the_oracles_bits(R, oracle_lib):
     print("MFMA kernel over 60 draws: max |dp| %.2e, packed tangent spaces equal %.5f (min %.5f)" % (worst_mfma, np.mean(packed_equal), np.min(packed_equal)))
     assert worst_mfma < 1e-6 and np.min(packed_equal) > 0.99
     r.close(); o.close()
+
+
+def test_random_environment_images_preprocess_to_the_oracles_bits(R, oracle_lib):
+    """Ten random equirectangular images -- odd sizes (not powers of two, width != 2 x height), eight orders of magnitude of radiance, black
+    regions, one with a single hot texel, one constant -- through the four environment kernels (equirect -> cube, mips, importance map, sum
+    pyramid) on both sides: every RGBA16F cube texel and every float of the 1024^2 map and its pyramid identical."""
+    rng = np.random.default_rng(77)
+    r = R(); o = oracle_lib.Oracle()
+    sizes = [(64, 32), (100, 50), (257, 129), (512, 256), (640, 200), (33, 77), (1024, 512), (8, 4), (300, 300), (2048, 1024)]
+    for k, (w, h) in enumerate(sizes):
+        img = (rng.random((h, w, 3)) ** 4 * 10.0 ** rng.uniform(-3, 5)).astype(np.float32)
+        if k % 3 == 0: img[: h // 2] = 0
+        if k == 4: img[:] = 0; img[h // 3, w // 5] = 3.0e5
+        if k == 5: img[:] = 0.25
+        eg = r.env_create(img); eo = o.env_create(img)
+        n, cube, pyr = r.env_read(eg); n2, cube2, pyr2 = o.env_read(eo)
+        assert n == n2 == w // 8 + 1
+        assert np.array_equal(cube, cube2), (k, w, h, int((cube != cube2).sum()))
+        assert np.array_equal(pyr.view(np.uint32), pyr2.view(np.uint32)), (k, w, h, int((pyr.view(np.uint32) != pyr2.view(np.uint32)).sum()))
+    r.close(); o.close()
