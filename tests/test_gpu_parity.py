@@ -332,9 +332,9 @@ def test_tonemap_matches_oracle(pair):
             cfg = abi.PtTonemapConfig(tm, 1.3, 7, dither)
             rgb_g, q_g = pair.r.tonemap(og, cfg, want_rgba8=True)
             rgb_o, q_o = po.tonemap(a, cfg, want_rgba8=True)          # same input image: isolates the tone mapper
-            ok = np.isfinite(rgb_o) & np.isfinite(rgb_g)
-            assert np.abs(rgb_g[ok] - rgb_o[ok]).max() < 2e-5
-            assert np.abs(q_g.astype(int) - q_o.astype(int)).max() <= 1
+            # log2 and pow are defined functions since round 3 (the AgX curve, the display transfer): the same bits as the oracle's for the same input
+            print("tone mapper %d dither %d: floats not bit-identical %d of %d, rgba8 different %d" % (tm, dither, int((rgb_g.view(np.uint32) != rgb_o.view(np.uint32)).sum()), rgb_g.size, int((q_g != q_o).sum())))
+            assert np.array_equal(rgb_g.view(np.uint32), rgb_o.view(np.uint32)) and np.array_equal(q_g, q_o)
 
 
 def _skin_setup(backend, s, use_mfma, t):
