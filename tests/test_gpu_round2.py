@@ -112,10 +112,9 @@ def test_refit_matches_full_rebuild_static_scene_plus_skinned_figure(R):
         dbg_full = [debug_image(r, s, h, d) for d in (abi.DEBUG_OUTPUT_HIT_KIND, abi.DEBUG_OUTPUT_TEXCOORD_0, abi.DEBUG_OUTPUT_VERTEX_NORMAL)]
         rad_full, s_full = radiance_image(r, s, h)
         for a, b in zip(dbg_refit, dbg_full):
-            assert (np.abs(a - b).max(axis=2) > 0).mean() < 2e-4, float((np.abs(a - b).max(axis=2) > 0).mean())
-        differ = float((np.abs(rad_refit - rad_full).max(axis=2) > 0).mean())
-        assert differ < 2e-3, differ
-        assert abs(int(s_refit.rays) - int(s_full.rays)) <= 1e-4 * s_full.rays
+            assert np.array_equal(a, b)        # (round 3: a ray's hit does not depend on the tree -- box gate + equal-distance rule, pt_traverse.h)
+        assert np.array_equal(rad_refit, rad_full), float((np.abs(rad_refit - rad_full).max(axis=2) > 0).mean())
+        assert int(s_refit.rays) == int(s_full.rays)
         # the figure is in the picture and it moved: the refitted frames of the two poses are different images
     print("accel: first build %.3f ms, rebuild %.3f ms, refits %s ms (%d triangles)" % (build_ms, rebuild_ms, ["%.3f" % x for x in refit_ms], s.triangles))
     assert max(refit_ms) < 0.6 * rebuild_ms, (refit_ms, rebuild_ms)
@@ -148,12 +147,12 @@ def test_builders_agree_and_ploc_visits_fewer_nodes(R):
         r.enable_counters(False)
         r.set_accel_builder(abi.BUILDER_LBVH if b == abi.BUILDER_PLOC else abi.BUILDER_PLOC)
         again = debug_image(r, s, h, abi.DEBUG_OUTPUT_TEXCOORD_0)
-        assert r.stats().accel_builds == 2 and (np.abs(again - imgs[name][1]).max(axis=2) > 0).mean() < 1e-4
+        assert r.stats().accel_builds == 2 and np.array_equal(again, imgs[name][1])
         r.close()
     for other in ("ploc", "reins"):
         for a, b in zip(imgs["lbvh"][:3], imgs[other][:3]):
-            assert (np.abs(a - b).max(axis=2) > 0).mean() < 1e-4          # exact-t ties on shared edges only
-        assert (np.abs(imgs["lbvh"][3] - imgs[other][3]).max(axis=2) > 0).mean() < 2e-3 and abs(rays["lbvh"] - rays[other]) <= 1e-4 * rays["lbvh"]
+            assert np.array_equal(a, b)                                   # three different trees, the same hits: bit-identical debug images ...
+        assert np.array_equal(imgs["lbvh"][3], imgs[other][3]) and rays["lbvh"] == rays[other]      # ... and radiance, ray for ray
     print("nodes per ray, config-4 class: radix tree %.2f, PLOC %.2f, PLOC + reinsertion %.2f" % (per_ray["lbvh"], per_ray["ploc"], per_ray["reins"]))
     assert per_ray["ploc"] < 0.9 * per_ray["lbvh"] and per_ray["reins"] < 0.98 * per_ray["ploc"]
 
@@ -252,7 +251,7 @@ def test_instance_table_diffing_identical_moved_and_reshaped(R):
     r2.set_instances(moved2)
     for img, d in zip(imgs, (abi.DEBUG_OUTPUT_HIT_KIND, abi.DEBUG_OUTPUT_VERTEX_NORMAL, abi.DEBUG_OUTPUT_COLOR)):
         other = debug_image(r2, s, h2, d)
-        assert (np.abs(img - other).max(axis=2) > 0).mean() < 5e-4
+        assert np.array_equal(img, other)
     assert np.abs(imgs[1] - ref).max() > 0.1                    # and it did move
     # a material swap alone touches no packet: neither build nor refit
     swapped = [abi.PtInstanceDesc.from_buffer_copy(bytes(d)) for d in moved]
@@ -274,7 +273,7 @@ def test_instance_table_diffing_identical_moved_and_reshaped(R):
     bigger = debug_image(r, s, h, abi.DEBUG_OUTPUT_HIT_KIND)
     assert r.stats().accel_refits == before + 1 and r.stats().accel_builds == 2
     r.request_rebuild()
-    assert (np.abs(bigger - debug_image(r, s, h, abi.DEBUG_OUTPUT_HIT_KIND)).max(axis=2) > 0).mean() < 5e-4
+    assert np.array_equal(bigger, debug_image(r, s, h, abi.DEBUG_OUTPUT_HIT_KIND))
     r.close(); r2.close()
 
 
@@ -423,7 +422,7 @@ def test_config2_helmet_class_matches_the_oracle(R, oracle_lib):
     og, b = p.render(frames=64)
     e = rel_l2(p.r.tonemap(og), po.tonemap(b))
     sg, so = p.r.stats(), p.o.counters()
-    assert abs(int(sg.rays) - so["rays"]) <= 3e-4 * so["rays"] + 2
+    assert int(sg.rays) == so["rays"]
     assert sg.rays_shadow > 0 and sg.rays_bounce > 0
     assert e <= 1e-3, e
     p.close()
@@ -466,7 +465,7 @@ def test_config3_sponza_class_at_8_bounces_matches_the_oracle(R, oracle_lib):
     a = p.r.readback(og)[..., :3].astype(np.float64); bb = b[..., :3].astype(np.float64)
     rel = np.abs(a - bb).max(axis=2) / np.maximum(np.abs(bb).max(axis=2), 1e-6)
     sg, so = p.r.stats(), p.o.counters()
-    assert abs(int(sg.rays) - so["rays"]) <= 2e-3 * so["rays"] + 2
+    assert int(sg.rays) == so["rays"]
     frac = float((rel > 1e-2).mean())
     assert np.median(rel) < 1e-6 and frac == 0.0, (float(np.median(rel)), frac)      # no pixel-sample beyond 1e-2 (0.0004 with the fp32 library sin / cos)
     # The image metric.  This scene amplifies rounding: tiled textures put texture coordinates at tens of units, glossy lobes turn a
@@ -588,7 +587,7 @@ def test_megakernel_mode_matches_the_oracle(R, oracle_lib):
     og, b = p.render(frames=32)
     e = rel_l2(p.r.tonemap(og), po.tonemap(b))
     sg, so = p.r.stats(), p.o.counters()
-    assert abs(int(sg.rays) - so["rays"]) <= 2e-4 * so["rays"] + 2
+    assert int(sg.rays) == so["rays"]
     assert e <= 1e-3, e
     p.close()
 
