@@ -206,7 +206,7 @@ def test_gpu_lbvh_closest_hits_match_bruteforce(R, oracle_lib):
         r.trace(st, s.execute_params(0, env_handle=hg["env"]), og)
         o.trace(st, s.execute_params(0, env_handle=ho["env"]), b)
         err = np.abs(r.readback(og)[..., :3] - b[..., :3]).max(axis=2)
-        assert (err > 1e-4).mean() < 0.002
+        assert (err > 0).sum() == 0             # (round 3: the tree, the oracle's tree and its exhaustive search return the same hits)
     st = r.stats()
     # wide nodes collapsed greedily from the n-1 binary LBVH nodes
     assert st.bvh_triangles == s.triangles and s.triangles // 32 <= st.bvh_nodes <= s.triangles - 1      # wide nodes (<= 8 children) over leaves of <= 3 triangles
@@ -469,7 +469,7 @@ def test_tables_larger_than_the_lds_caches(R, oracle_lib):
         st = copy_settings(s.settings); st.debug_output = dbg; st.flags &= ~abi.FLAG_ACCUMULATE; st.use_frame_as_seed = 0; st.seed = 4
         og, b = p.render(settings=st)
         err = np.abs(p.r.readback(og)[..., :3] - b[..., :3]).max(axis=2)
-        assert (err > 1e-4).mean() < 0.003, (abi.DEBUG_OUTPUT_NAMES[dbg], float((err > 1e-4).mean()))
+        assert (err > 0).sum() == 0, (abi.DEBUG_OUTPUT_NAMES[dbg], int((err > 0).sum()))
     import oracle.pyoracle as po
     og, b = p.render(frames=64)
     e = rel_l2(p.r.tonemap(og), po.tonemap(b))
@@ -511,7 +511,7 @@ def test_fullsize_scene_hits_and_radiance_match_the_oracle(R, oracle_lib):
         st = copy_settings(s.settings); st.debug_output = dbg; st.flags &= ~abi.FLAG_ACCUMULATE; st.use_frame_as_seed = 0; st.seed = 3
         og, b = p.render(settings=st)
         err = np.abs(p.r.readback(og)[..., :3] - b[..., :3]).max(axis=2)
-        assert (err > 1e-4).mean() < 0.002, (abi.DEBUG_OUTPUT_NAMES[dbg], float((err > 1e-4).mean()))
+        assert (err > 0).sum() == 0, (abi.DEBUG_OUTPUT_NAMES[dbg], int((err > 0).sum()))
     # Radiance per pixel-sample, seed matched.  The primary hits are identical (above).  This scene amplifies rounding -- it tiles its textures
     # (texture coordinates of tens of units) and glossy lobes turn a perturbed shading normal into a different path -- and an FMA-contracting
     # build parted from the plain-arithmetic oracle in 0.3 % of the pixel-samples at one bounce and 2 % at four.  Built without contraction
