@@ -168,8 +168,8 @@ PT_DEV void pt_sincos(float x, float& s, float& c) {
 // direction -> importance-map texel mapping of the environment pdf (a last bit picks the neighbouring texel once in ~10^6 lookups: a MIS
 // weight off by up to a percent), pow and exp in the sheen lobe (five pows and two exps per evaluation).  Through double (like sin / cos)
 // they cost 7.7 ms of a 22.6 ms launch (measured: ocml's double atan2, log2, exp2 are long).  These: atan2 nothing measurable; pow / exp
-// 0.45 ms on the Sponza-class scene, whose curtains (3 % of the hits) put a sheen lane into most waves of the shade stage -- v_log_f32 /
-// v_exp_f32 were 3 instructions per pow, this is ~70 (0.8 ms before the view-dependent half of the sheen lobe was hoisted out of the three
+// 0.35 ms on the Sponza-class scene, whose curtains (3 % of the hits) put a sheen lane into most waves of the shade stage -- v_log_f32 /
+// v_exp_f32 were 3 instructions per pow, this is ~55 (0.8 ms before the view-dependent half of the sheen lobe was hoisted out of the three
 // evaluations a hit makes, pt_shading.h prepare_sheen; as real calls instead of inlined code 1.0 ms).  PT_CO_TRANSCENDENTALS / PT_CO_ATAN2 /
 // PT_CO_POW = 0: the library routines (A/B).
 #ifndef PT_CO_TRANSCENDENTALS
@@ -194,13 +194,10 @@ PT_DEV float co_atan2(float y, float x) {
 PT_DEV float co_log2(float x) {
     if (!(x > 0.0f)) return x == 0.0f ? -__builtin_inff() : __builtin_nanf("");
     if (x == __builtin_inff()) return x;
-    int e = 0;
-    if (x < 1.17549435e-38f) { x *= 16777216.0f; e = -24; }  // subnormal
-    const uint32_t b = __float_as_uint(x);
-    e += (int)(b >> 23) - 127;
-    float m = __uint_as_float((b & 0x007fffffu) | 0x3f800000u);   // [1, 2)
-    if (m > 1.41421354f) { m *= 0.5f; e += 1; }              // (sqrt 1/2, sqrt 2]
-    const float t = (m - 1.0f) / (m + 1.0f), s = t * t;
+    float m = __builtin_amdgcn_frexp_mantf(x);               // x = m 2^e, m in [1/2, 1): exact, subnormal arguments included (frexpf in the oracle)
+    int e = __builtin_amdgcn_frexp_expf(x);
+    if (m < 0.707106769f) { m *= 2.0f; e -= 1; }             // [sqrt 1/2, sqrt 2)
+    const float t = fdiv(m - 1.0f, m + 1.0f), s = t * t;     // (operands and quotient inside fdiv's contract: the IEEE quotient)
     float q = 0x1.ba1838p-2f;
     q = q * s + 0x1.274720p-1f; q = q * s + 0x1.ec70e6p-1f; q = q * s + 0x1.715476p+1f;
     return (float)e + t * q;
@@ -210,10 +207,7 @@ PT_DEV float co_exp2_reduced(float r) {                       // 2^r, r in [-1/2
     q = q * r + 0x1.5f0896p-10f; q = q * r + 0x1.3b2a1cp-7f; q = q * r + 0x1.c6af6cp-5f; q = q * r + 0x1.ebfbe0p-3f; q = q * r + 0x1.62e430p-1f;
     return 1.0f + r * q;
 }
-PT_DEV float co_scale2(float v, float n) {                       // v * 2^n, n an integer in [-125, 128]: two exact factors (2^128 is not a float)
-    const int k = (int)n, h = k / 2, g = k - h;
-    return v * __uint_as_float((uint32_t)(h + 127) << 23) * __uint_as_float((uint32_t)(g + 127) << 23);
-}
+PT_DEV float co_scale2(float v, float n) { return __builtin_amdgcn_ldexpf(v, (int)n); }     // v * 2^n, n an integer in [-125, 128]: exact, or +inf (ldexpf in the oracle)
 PT_DEV float co_exp2(float p) {
     if (!(p == p)) return p;
     if (p >= 128.0f) return __builtin_inff();

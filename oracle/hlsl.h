@@ -130,12 +130,9 @@ inline float o_atan2(float y, float x) {
 inline float o_log2(float x) {
     if (!(x > 0.0f)) return x == 0.0f ? -INFINITY : NAN;
     if (x == INFINITY) return x;
-    int e = 0;
-    if (x < 1.17549435e-38f) { x *= 16777216.0f; e = -24; }
-    const uint32_t b = o_bits(x);
-    e += (int)(b >> 23) - 127;
-    float m = o_float((b & 0x007fffffu) | 0x3f800000u);
-    if (m > 1.41421354f) { m *= 0.5f; e += 1; }
+    int e;
+    float m = frexpf(x, &e);                                 // [1/2, 1), exact
+    if (m < 0.707106769f) { m *= 2.0f; e -= 1; }
     const float t = (m - 1.0f) / (m + 1.0f), s = t * t;
     float q = 0x1.ba1838p-2f;
     q = q * s + 0x1.274720p-1f; q = q * s + 0x1.ec70e6p-1f; q = q * s + 0x1.715476p+1f;
@@ -146,10 +143,7 @@ inline float o_exp2_reduced(float r) {                       // 2^r, r in [-1/2,
     q = q * r + 0x1.5f0896p-10f; q = q * r + 0x1.3b2a1cp-7f; q = q * r + 0x1.c6af6cp-5f; q = q * r + 0x1.ebfbe0p-3f; q = q * r + 0x1.62e430p-1f;
     return 1.0f + r * q;
 }
-inline float o_scale2(float v, float n) {                       // v * 2^n, n an integer in [-125, 128]: two exact factors (2^128 is not a float)
-    const int k = (int)n, h = k / 2, g = k - h;
-    return v * o_float((uint32_t)(h + 127) << 23) * o_float((uint32_t)(g + 127) << 23);
-}
+inline float o_scale2(float v, float n) { return ldexpf(v, (int)n); }                        // v * 2^n, n an integer in [-125, 128]: exact, or +inf
 inline float o_exp2(float p) {
     if (!(p == p)) return p;
     if (p >= 128.0f) return INFINITY;
