@@ -26,7 +26,7 @@ t0 = time.time()
 print("%s %dx%d, max_bounces %d, %d triangles: GPU against the oracle, sample by sample" % (s.name, s.width, s.height, s.settings.max_bounces, s.triangles), flush=True)
 for f in range(N):
     r.trace(st, s.execute_params(f, env_handle=hg["env"]), og); o.trace(st, s.execute_params(f, env_handle=ho["env"]), b); st.reset = 0
-    if (f + 1) in (1, 4, 16, 64, 256) or f + 1 == N:
+    if (f + 1) in (1, 4, 16, 64, 96, 128, 160, 192, 224, 256, 384, 512) or f + 1 == N:
         ta, tb = r.tonemap(og), po.tonemap(b)
         ok = np.isfinite(ta).all(axis=2) & np.isfinite(tb).all(axis=2)
         e = float(np.sqrt(((ta[ok].astype(np.float64) - tb[ok]) ** 2).sum() / (tb[ok].astype(np.float64) ** 2).sum()))
