@@ -705,6 +705,15 @@ PT_DEV vec3 gltf_bsdf(const float* lut, const Surface& s, vec3 v, vec3 l, int mo
     float hdl = dot(h, l), hdv = dot(h, v);
     float h_dot_abs_l = dot(normalize(v3(ll.x, ll.y, fabsf(ll.z)) + vl), vl);
     bool refl = mode != 2, trans = mode != 1;
+    // the coat first (PT_COAT_FIRST; it is the LAST term of the shader's expression, :318-324): its inputs are the world-space n, v, h, l, which
+    // nothing after it needs -- evaluated at the end they stayed live through the whole function in a kernel that has no register to spare
+    float cndv = dot(n, v), cndh = dot(n, h), cndl = dot(n, l);                    // (sic) shading normal
+#ifndef PT_PROBE_BASE_ONLY
+    const float cc = refl ? saturate(cndl) * specular_brdf(s.cc_rough, cndl, cndv, cndh, hdl, hdv) : 0.f;
+#else
+    const float cc = 0.f;
+#endif
+    const float coat_w = fresnel_coat_w(s.clearcoat, cndv);
     float spec = refl ? saturate(ll.z) * aniso_specular_brdf(s.ax, s.ay, vl, hl, ll) : 0.f;
     vec3 diffuse = refl ? saturate(ll.z) * (s.albedo / kPi) : v3(0);
     vec3 transmission = v3(0);
@@ -753,13 +762,7 @@ PT_DEV vec3 gltf_bsdf(const float* lut, const Surface& s, vec3 v, vec3 l, int mo
         if (ms != 0.0f) scaling = hmin(1.0f - ms * sheen_e(lut, sa, vl.z), 1.0f - ms * sheen_e(lut, sa, ll.z));
         material = s.sheen_color * sheen + material * scaling;
     }
-    float cndv = dot(n, v), cndh = dot(n, h), cndl = dot(n, l);                    // (sic) shading normal
-#ifndef PT_PROBE_BASE_ONLY
-    float cc = refl ? saturate(cndl) * specular_brdf(s.cc_rough, cndl, cndv, cndh, hdl, hdv) : 0.f;
-#else
-    float cc = 0.f;
-#endif
-    return lerp3(material, v3(cc), fresnel_coat_w(s.clearcoat, cndv));             // FresnelCoat(1.5, ...)
+    return lerp3(material, v3(cc), coat_w);                                         // FresnelCoat(1.5, ...)
 }
 
 // ---------------------------------------------------------------- sampling (Sampling.hlsli, Transforms.hlsli)
