@@ -803,3 +803,28 @@ def test_random_environment_images_preprocess_to_the_oracles_bits(R, oracle_lib)
         assert np.array_equal(cube, cube2), (k, w, h, int((cube != cube2).sum()))
         assert np.array_equal(pyr.view(np.uint32), pyr2.view(np.uint32)), (k, w, h, int((pyr.view(np.uint32) != pyr2.view(np.uint32)).sum()))
     r.close(); o.close()
+
+
+def test_animated_figure_refitted_every_frame_matches_the_oracle_pose_for_pose(R, oracle_lib):
+    """The dynamic path frame by frame: sixteen poses of the walk cycle (with two morph targets breathing in and out), on the GPU skin ->
+    REFIT (UpdateDynamicBlas) -> one sample, in the oracle skin -> full CPU build -> one sample: no pixel-sample beyond 1e-3, equal ray
+    counts, every frame -- the refitted tree (topology of the first pose, boxes of the current one) returns the hits of a fresh one."""
+    s = scenes.skinned_figure(480, 270)
+    scenes.add_morph_targets(s)
+    r = R(); hg = s.upload(r); o = oracle_lib.Oracle(); ho = s.upload(o)
+    bg = scenes.SkinBinding(r, s, hg, 0, 0, morph=[(0, 0.0), (1, 0.0)]); bo = scenes.SkinBinding(o, s, ho, 0, 0, morph=[(0, 0.0), (1, 0.0)])
+    og = r.create_output(s.width, s.height); b = np.zeros((s.height, s.width, 4), np.float32)
+    st = copy_settings(s.settings); st.flags &= ~abi.FLAG_ACCUMULATE
+    for f in range(16):
+        t = f / 8.0
+        for bind in (bg, bo):
+            bind.params.morph_weights[0] = 0.5 + 0.5 * np.sin(3 * t); bind.params.morph_weights[1] = 0.5 - 0.5 * np.cos(2 * t)
+            bind.pose(t)
+        r.reset_stats(); o.counters()
+        r.trace(st, s.execute_params(f, env_handle=hg["env"]), og); o.trace(st, s.execute_params(f, env_handle=ho["env"]), b)
+        A = r.readback(og)[..., :3].astype(np.float64); B = b[..., :3].astype(np.float64)
+        rel = np.abs(A - B).max(axis=2) / np.maximum(np.abs(B).max(axis=2), 1e-4)
+        assert (rel > 1e-3).sum() == 0 and r.stats().rays == o.counters()["rays"], (f, int((rel > 1e-3).sum()), r.stats().rays)
+    q = r.stats()
+    assert q.accel_builds == 1 and q.accel_refits >= 15, (q.accel_builds, q.accel_refits)
+    r.close(); o.close()
