@@ -438,8 +438,16 @@ PT_DEV void env_prepass(const SceneRec& sc, const FrameConstants& fc, const WfBu
 #define PT_FUSE_TRAVERSAL 1   // the shadow rays of a bounce and the closest-hit rays of the next in one launch (k_wf_traverse)
 #endif
 // `bounce` = the bounce whose shade stage follows: it fills closest queue cur ^ 1 and the shadow counter of that bounce.
-template <bool COUNT>
+// DEFAULTS (k_wf_trace, k_wf_traverse): a copy compiled for the settings that leave the rays' flags alone -- no back-face culling, no alpha
+// shadows, no indirect-environment-only mask (the application's defaults): ray flags 0, mask 0xff and an accept-first shadow search as
+// constants take the other searches' code out of the loop (13.87 against 14.04 ms of traversal per launch).  launch_wavefront picks it.
+constexpr uint32_t kTravFlagMask = PT_FLAG_CULL_BACKFACE | PT_FLAG_ALPHA_SHADOWS | PT_FLAG_INDIRECT_ENVIRONMENT_ONLY;
+#ifndef PT_TRAV_SPECIALISE
+#define PT_TRAV_SPECIALISE 1
+#endif
+template <bool COUNT, bool DEFAULTS>
 __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_trace(SceneRec sc, FrameConstants fc, WfBuffers wf, int cur, int bounce, uint32_t rf, uint32_t rmask, Counters* __restrict__ counters) {
+    if (DEFAULTS) { rf = 0; rmask = 0xff; }
     __shared__ int s_stack[kStackLds * kBlock];
     stage_luts(sc);
     const ShardView sv = shard_view(wf);
@@ -457,9 +465,10 @@ __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_trace(SceneRec sc
 // one launch serves both: a wave that runs out of shadow rays goes straight on to pull bounce rays, and the frame has two
 // grid-wide synchronisations per bounce instead of three (each one ends on its slowest wave: ~0.07 ms of a 5.5-ms 1-spp frame).
 // `nxt` = closest queue the shade stage of `bounce` filled.  Zeroes what the shade stage of bounce + 1 fills.
-template <bool COUNT>
+template <bool COUNT, bool DEFAULTS>
 __global__ __launch_bounds__(kBlock, PT_TRACE_WAVES) void k_wf_traverse(SceneRec sc, FrameConstants fc, WfBuffers wf, int nxt, int bounce, uint32_t rf, uint32_t rmask, uint32_t flags,
                                                                         Counters* __restrict__ counters) {
+    if (DEFAULTS) { rf = 0; rmask = 0xff; flags &= ~kTravFlagMask; }
     __shared__ int s_stack[kStackLds * kBlock];
     stage_luts(sc);
     const ShardView sv = shard_view(wf);
@@ -903,6 +912,20 @@ hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4
             rmask = (flags & PT_FLAG_INDIRECT_ENVIRONMENT_ONLY) ? 0 : 0xff;
         }
     };
+    // the traversal kernels compiled for rays with no flags, if that is what this frame's settings give them
+    const bool trav_defaults = PT_TRAV_SPECIALISE && (flags & kTravFlagMask) == 0;
+    auto launch_trace = [&](dim3 grid, const WfBuffers& w, int cur, int b, uint32_t rf, uint32_t rmask) {
+        if (trav_defaults) { if (count) hipLaunchKernelGGL((k_wf_trace<true, true>), grid, block, 0, stream, sc, fc, w, cur, b, rf, rmask, counters);
+                             else hipLaunchKernelGGL((k_wf_trace<false, true>), grid, block, 0, stream, sc, fc, w, cur, b, rf, rmask, counters); }
+        else { if (count) hipLaunchKernelGGL((k_wf_trace<true, false>), grid, block, 0, stream, sc, fc, w, cur, b, rf, rmask, counters);
+               else hipLaunchKernelGGL((k_wf_trace<false, false>), grid, block, 0, stream, sc, fc, w, cur, b, rf, rmask, counters); }
+    };
+    auto launch_traverse = [&](dim3 grid, const WfBuffers& w, int nxt, int b, uint32_t rf, uint32_t rmask) {
+        if (trav_defaults) { if (count) hipLaunchKernelGGL((k_wf_traverse<true, true>), grid, block, 0, stream, sc, fc, w, nxt, b, rf, rmask, flags, counters);
+                             else hipLaunchKernelGGL((k_wf_traverse<false, true>), grid, block, 0, stream, sc, fc, w, nxt, b, rf, rmask, flags, counters); }
+        else { if (count) hipLaunchKernelGGL((k_wf_traverse<true, false>), grid, block, 0, stream, sc, fc, w, nxt, b, rf, rmask, flags, counters);
+               else hipLaunchKernelGGL((k_wf_traverse<false, false>), grid, block, 0, stream, sc, fc, w, nxt, b, rf, rmask, flags, counters); }
+    };
     // the shade kernel compiled for this frame's flags, if there is one (k_wf_shade)
     const uint32_t shade_bits = flags & kShadeFlagMask;
     const int shade_variant = (!PT_SHADE_SPECIALISE || fc.debug_output != PT_DEBUG_OUTPUT_NONE) ? 0 : (shade_bits == kShadeDefaults ? 1 : (shade_bits == kShadeDefaultsNoLights ? 2 : 0));
@@ -945,11 +968,9 @@ hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4
         ray_flags(0, rf, rmask);
 #if PT_LATE_GRID
         const dim3 g0 = cap(stage, env_trace_bps);
-        if (count) hipLaunchKernelGGL(k_wf_trace<true>, g0, block, 0, stream, sc, fc, wf_of(g0), 0, 0, rf, rmask, counters);
-        else hipLaunchKernelGGL(k_wf_trace<false>, g0, block, 0, stream, sc, fc, wf_of(g0), 0, 0, rf, rmask, counters);
+        launch_trace(g0, wf_of(g0), 0, 0, rf, rmask);
 #else
-        if (count) hipLaunchKernelGGL(k_wf_trace<true>, stage, block, 0, stream, sc, fc, wf, 0, 0, rf, rmask, counters);
-        else hipLaunchKernelGGL(k_wf_trace<false>, stage, block, 0, stream, sc, fc, wf, 0, 0, rf, rmask, counters);
+        launch_trace(stage, wf, 0, 0, rf, rmask);
 #endif
         mark(STAGE_TRACE);
     }
@@ -967,8 +988,7 @@ hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4
         uint32_t rf, rmask;
         ray_flags(b + 1, rf, rmask);
         if (b + 1 < iterations) {
-            if (count) hipLaunchKernelGGL(k_wf_traverse<true>, gt, block, 0, stream, sc, fc, wt, cur ^ 1, b, rf, rmask, flags, counters);
-            else hipLaunchKernelGGL(k_wf_traverse<false>, gt, block, 0, stream, sc, fc, wt, cur ^ 1, b, rf, rmask, flags, counters);
+            launch_traverse(gt, wt, cur ^ 1, b, rf, rmask);
         } else {                                                                                      // the last vertex pushes no bounce ray
             if (count) hipLaunchKernelGGL(k_wf_shadow<true>, gt, block, 0, stream, sc, wt, b, flags, fc.max_ray_length, counters);
             else hipLaunchKernelGGL(k_wf_shadow<false>, gt, block, 0, stream, sc, wt, b, flags, fc.max_ray_length, counters);
@@ -980,8 +1000,7 @@ hipError_t launch_wavefront(const SceneRec& sc, const FrameConstants& fc, float4
         const int cur = b & 1;
         uint32_t rf, rmask;
         ray_flags(b, rf, rmask);
-        if (count) hipLaunchKernelGGL(k_wf_trace<true>, stage, block, 0, stream, sc, fc, wf, cur, b, rf, rmask, counters);
-        else hipLaunchKernelGGL(k_wf_trace<false>, stage, block, 0, stream, sc, fc, wf, cur, b, rf, rmask, counters);
+        launch_trace(stage, wf, cur, b, rf, rmask);
         mark(STAGE_TRACE);
         launch_shade(stage, wf, cur, b);
         mark(STAGE_SHADE);
