@@ -348,7 +348,7 @@ PT_DEV void stage_instances(const SceneRec& sc) {          // 256-thread workgro
 }
 PT_DEV ShadeInst load_shade_inst(const SceneRec& sc, uint32_t id) {
     float4 q[6];
-    if (id < kInstCacheMax) {
+    if (sc.small_tables || id < kInstCacheMax) {
 #pragma unroll
         for (int k = 0; k < 6; k++) q[k] = pt_lds_inst[id * 6u + k];
     } else shade_inst_pack(sc.instances[id], q);
@@ -438,7 +438,7 @@ PT_DEV bool slot_bound(uint32_t mask, int slot) { return (mask >> slot) & 1u; }
 constexpr uint32_t kMatCacheMax = 96;
 constexpr uint32_t kMatCacheRecs = 17;                     // float4 per material: 8 header + 3 slots x 3
 static __shared__ float4 pt_lds_mat[kMatCacheMax * kMatCacheRecs];
-PT_DEV bool materials_cached(const SceneRec& sc) { return sc.n_materials <= kMatCacheMax; }
+PT_DEV bool materials_cached(const SceneRec& sc) { return sc.small_tables || sc.n_materials <= kMatCacheMax; }
 PT_DEV void stage_materials(const SceneRec& sc) {          // call once per workgroup, all threads
     if (materials_cached(sc)) {
         const uint32_t total = sc.n_materials * kMatCacheRecs;
@@ -991,7 +991,7 @@ PT_DEV void stage_lights(const SceneRec& sc, int num_of_lights) {   // 256-threa
 }
 PT_DEV pt_light load_light(const SceneRec& sc, uint32_t li, bool& cone_terms_staged) {
     float4 q[4];
-    cone_terms_staged = li < (uint32_t)kLightCacheMax;
+    cone_terms_staged = sc.small_tables || li < (uint32_t)kLightCacheMax;
     if (cone_terms_staged) { const float4* p = pt_lds_light + li * 4u; q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; q[3] = p[3]; }
     else { const float4* p = (const float4*)sc.lights + (size_t)li * 4u; q[0] = gload_f4(p); q[1] = gload_f4(p + 1); q[2] = gload_f4(p + 2); q[3] = gload_f4(p + 3); }
     pt_light l;

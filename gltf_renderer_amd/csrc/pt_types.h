@@ -211,6 +211,8 @@ struct SceneRec {
     // deep_entries == 0 (every ordinary scene): one scalar test per pop / slow push, nothing else.
     int32_t* deep_stack;
     uint32_t deep_entries, deep_lanes;
+    uint32_t small_tables;            // 1: every instance row, material and light of the scene is in the shade stage's LDS copies (set as a CONSTANT by the kernel
+                                      // copy compiled for such scenes, k_wf_shade<.., true>: the table lookups then lose their global-memory branch); 0 elsewhere
 };
 
 // SceneConstants (PathTracer.lib.hlsl:10-30) plus the tile shard of this rank.
